@@ -1,0 +1,172 @@
+"""ctypes front-end of oracle/bsp_oracle.c (TEST INFRASTRUCTURE ONLY).
+
+Parity status: PINNED -- checked in tests/test_oracle_golden.py against fixtures produced
+by the compiled reference (tests/golden/make_golden.py): derived sizes, knots, Gauss-Legendre
+rule and Aind bit-for-bit; S, T, V bit-for-bit; U_l bit-for-bit; spectra within the stated
+LAPACK-vs-LAPACK tolerance (the reference's DSYGV lives in Intel MKL, version unpinned --
+matrices.f90:248, src/Makefile:23; the oracle uses netlib LAPACK 3.12 DSYGV from scipy's
+OpenBLAS, the same library the compiled reference in oracle/_ref is linked to, or the plain
+C chain orc_dsygv for small sizes).
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class OrcCfg(C.Structure):
+    _fields_ = [
+        ("kind_grid", C.c_int), ("k", C.c_int), ("ka", C.c_int), ("nfun", C.c_int),
+        ("kind_bc1", C.c_int), ("kind_bc2", C.c_int),
+        ("ra", C.c_double), ("rb", C.c_double), ("rmax", C.c_double),
+        ("n0_ini", C.c_int), ("l_ini", C.c_int), ("m_ini", C.c_int), ("l_fin", C.c_int),
+        ("lmax", C.c_int), ("kind_pot", C.c_int),
+        ("emax_fin", C.c_double), ("zatom", C.c_double),
+        ("nbc1", C.c_int), ("nbc2", C.c_int), ("nkp", C.c_int), ("nointv", C.c_int),
+        ("nintv_exp", C.c_int), ("nintv_lin", C.c_int), ("imax", C.c_int),
+        ("gsize", C.c_double),
+        ("numn", C.c_int * 3), ("ntot", C.c_int),
+        ("alphan", C.c_double * 3),
+        ("bl", C.c_double * 4),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liborc.so")
+    src = os.path.join(_HERE, "bsp_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared",
+                               "-o", so, src, "-lm"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_selpot.restype = C.c_double
+        _LIB.orc_selpot.argtypes = [C.POINTER(OrcCfg), C.c_double]
+        _LIB.orc_gauleg.argtypes = [C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+        _LIB.orc_interv.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_int)]
+        _LIB.orc_bsplvb.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# VARS_BSP / VARS_TISE defaults, ReadInputs.f90:27-36, :75-84
+DEFAULTS = dict(kind_grid=0, ra=0.0, rb=0.0, rmax=0.0, k=0, ka=0, nfun=0, kind_bc1=0, kind_bc2=0,
+                n0_ini=1, l_ini=0, m_ini=0, l_fin=0, lmax=0, emax_fin=-1.0, zatom=1.0, kind_pot=0)
+
+
+def make_cfg(**kw):
+    """Build an OrcCfg from namelist values (lower-case keys) and derive sizes."""
+    vals = dict(DEFAULTS)
+    for key, v in kw.items():
+        key = key.lower()
+        if key in vals:
+            vals[key] = v
+    c = OrcCfg()
+    for key, v in vals.items():
+        setattr(c, key, v)
+    lib().orc_derive(C.byref(c))
+    return c
+
+
+def grid(c):
+    rt = np.zeros(c.nkp)
+    aind = np.zeros(2 * c.nfun)
+    lib().orc_grid(C.byref(c), _p(rt), _p(aind))
+    xg = np.zeros(c.ka)
+    wg = np.zeros(c.ka)
+    lib().orc_gauleg(-1.0, 1.0, _p(xg), _p(wg), c.ka)
+    return rt, aind, xg, wg
+
+
+def matrix_svt(c, rt, aind, xg, wg):
+    """Reference-faithful dense assembly: returns S, V, T (n,n) and U (lmax+1,n,n), [i,j] indexed."""
+    n = c.nfun
+    S = np.zeros(n * n); V = np.zeros(n * n); T = np.zeros(n * n); U = np.zeros(n * n * (c.lmax + 1))
+    st = lib().orc_matrix_svt(C.byref(c), _p(rt), _p(aind), _p(xg), _p(wg), _p(S), _p(V), _p(T), _p(U))
+    if st:
+        raise RuntimeError("oracle: FATAL ERROR - BSPLVB (status %d)" % st)
+    f = lambda a: a.reshape(n, n).T.copy()
+    return f(S), f(V), f(T), np.stack([f(U[l * n * n:(l + 1) * n * n]) for l in range(c.lmax + 1)])
+
+
+def assemble_bands(c, rt, aind, xg, wg, l0=0, nl=None):
+    """Upper bands: SB[d,i] = S(i,i+d); HB[l,d,i] = ((T+U_l)+V)(i,i+d)  (matrices.f90:244)."""
+    if nl is None:
+        nl = c.lmax + 1 - l0
+    n, k = c.nfun, c.k
+    SB = np.zeros((k, n)); HB = np.zeros((nl, k, n))
+    st = lib().orc_assemble_bands(C.byref(c), _p(rt), _p(aind), _p(xg), _p(wg), l0, nl, _p(SB), _p(HB))
+    if st:
+        raise RuntimeError("oracle: FATAL ERROR - BSPLVB (status %d)" % st)
+    return SB, HB
+
+
+def band_to_dense_upper(B):
+    k, n = B.shape
+    M = np.zeros((n, n))
+    for d in range(k):
+        idx = np.arange(n - d)
+        M[idx, idx + d] = B[d, : n - d]
+    return M
+
+
+def dsygv(H_upper, S_upper, vectors=True, impl="lapack"):
+    """DSYGV(1,'V','U') on dense matrices whose upper triangles hold H and S (matrices.f90:248).
+
+    impl='lapack': netlib LAPACK 3.12 through scipy (the published algorithm of the reference's
+    third-party dependency); impl='c': the plain C chain in bsp_oracle.c (small n)."""
+    n = H_upper.shape[0]
+    if impl == "c":
+        A = np.asfortranarray(np.triu(H_upper) + np.triu(H_upper, 1).T).copy(order="F")
+        B = np.asfortranarray(np.triu(S_upper) + np.triu(S_upper, 1).T).copy(order="F")
+        w = np.zeros(n)
+        lib().orc_dsygv.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        info = lib().orc_dsygv(n, _p(A), _p(B), _p(w))
+        return w, A, info
+    return _dsygv_scipy(H_upper, S_upper, vectors)
+
+
+def _dsygv_scipy(H_upper, S_upper, vectors):
+    from scipy.linalg import lapack
+    res = lapack.dsygv(np.asfortranarray(H_upper), np.asfortranarray(S_upper), itype=1,
+                       jobz="V" if vectors else "N", uplo="U")
+    # scipy returns (w, v/a, info) for dsygv
+    w, v, info = res[0], res[1], res[-1]
+    return w, v, info
+
+
+def write_wf(c, rt, ci, npts=10000):
+    r = np.zeros(npts + 1); u = np.zeros(npts + 1)
+    ci = np.ascontiguousarray(ci, dtype=np.float64)
+    st = lib().orc_write_wf(C.byref(c), _p(rt), _p(ci), len(ci), npts, _p(r), _p(u))
+    if st:
+        raise RuntimeError("FATAL ERROR - BSPLVB")
+    return r, u
+
+
+def solve_all(c, vectors_for=None):
+    """Whole path on the CPU: returns E[lmax+1, nfun] (and the eigenvector of (l_ini, n0_ini))."""
+    rt, aind, xg, wg = grid(c)
+    SB, HB = assemble_bands(c, rt, aind, xg, wg)
+    S = band_to_dense_upper(SB)
+    E = np.zeros((c.lmax + 1, c.nfun))
+    vec = None
+    for l in range(c.lmax + 1):
+        want_v = (l == c.l_ini)
+        w, v, info = dsygv(band_to_dense_upper(HB[l]), S, vectors=want_v)
+        if info != 0:
+            raise RuntimeError("ERROR DIAGONALIZING THE MATRIX! %d (l = %d)" % (info, l))
+        E[l] = w
+        if want_v:
+            vec = v[:, c.n0_ini - 1].copy()
+    return E, vec, (rt, aind, xg, wg)

@@ -1,0 +1,49 @@
+#!/usr/bin/env bash
+# build_ref.sh -- compile the UNMODIFIED reference sources where they lie
+# (/root/reference/src) into oracle/_ref/ (git-ignored; binaries only).  TEST INFRASTRUCTURE.
+#
+# Outputs:
+#   oracle/_ref/Bsp_Atom_ref.x  the reference program itself (stdin namelist -> stdout,
+#                               Enl.dat, wf_n0.dat), `INQUIRE(DIRECTORY=` (an ifort-only
+#                               extension, Bsp_Atom.f90:59) spelled `INQUIRE(FILE=` in a
+#                               temporary stream so that flang accepts it;
+#   oracle/_ref/ref_dump.x      ref_dump_driver.f90 + the same reference objects; also
+#                               writes ref_dump.bin (module state) for the golden fixtures.
+# LAPACK/BLAS: scipy's bundled OpenBLAS (LAPACK 3.12.0) through lapack_forward.c, since the
+# reference's `-mkl` is not in this image.  No reference source is copied into the repo:
+# the two filtered translation units live in a mktemp dir that is removed on exit.
+set -euo pipefail
+REF=${BSP_REFERENCE:-/root/reference}
+HERE=$(cd "$(dirname "$0")" && pwd)
+OUT=$HERE/../_ref
+[ -d "$REF/src" ] || { echo "build_ref: $REF/src not present (GPU box?) - skipping"; exit 0; }
+FC=${FC:-/opt/rocm/lib/llvm/bin/flang}
+[ -x "$FC" ] || { echo "build_ref: no flang at $FC - skipping"; exit 0; }
+SCIPY_LIBS=$(python3 -c "import scipy,os;print(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)),'scipy.libs'))")
+OPENBLAS=$(ls "$SCIPY_LIBS"/libscipy_openblas*.so | head -1)
+mkdir -p "$OUT/obj"
+TMP=$(mktemp -d /tmp/bspref.XXXXXX); trap 'rm -rf "$TMP"' EXIT
+cd "$OUT/obj"
+FFLAGS="-O2"
+"$FC" $FFLAGS -c "$REF/src/Modules.f90" -o Modules.o
+for f in ReadInputs matrices PhotoIon WriteWF grid CubicSpline bsplvb interv Ang_Ints Ang_Ints_Aux \
+         TorusFuns TorusFunsInts Funs_AssLegendre Funs_AssLaguerre Funs_SphHarms Funs_Bessel; do
+  "$FC" $FFLAGS -c "$REF/src/$f.f90" -o $f.o
+done
+"$FC" $FFLAGS -ffixed-form -c "$REF/src/Funs_WignerSymbols.for" -o Funs_WignerSymbols.o
+# the program unit, one token made portable
+sed "s/INQUIRE( DIRECTORY='CSs'/INQUIRE( FILE='CSs\/.'/" "$REF/src/Bsp_Atom.f90" > "$TMP/main_unit.f90"
+"$FC" $FFLAGS -c "$TMP/main_unit.f90" -o Bsp_Atom.o
+# WRITE_WF / END_PROG only (everything after the program unit), for the dump driver
+sed -n '/^ *SUBROUTINE WRITE_WF/,$p' "$REF/src/Bsp_Atom.f90" > "$TMP/subs_unit.f90"
+"$FC" $FFLAGS -c "$TMP/subs_unit.f90" -o Bsp_Atom_subs.o
+"$FC" $FFLAGS -c "$HERE/ref_dump_driver.f90" -o ref_dump_driver.o
+gcc -O2 -c "$HERE/lapack_forward.c" -o lapack_forward.o
+COMMON="Modules.o ReadInputs.o matrices.o PhotoIon.o WriteWF.o grid.o CubicSpline.o bsplvb.o interv.o \
+ Ang_Ints.o Ang_Ints_Aux.o TorusFuns.o TorusFunsInts.o Funs_AssLegendre.o Funs_AssLaguerre.o \
+ Funs_SphHarms.o Funs_Bessel.o Funs_WignerSymbols.o lapack_forward.o"
+LINK="$OPENBLAS -Wl,-rpath,$SCIPY_LIBS -lm"
+"$FC" -o "$OUT/Bsp_Atom_ref.x" Bsp_Atom.o $COMMON $LINK
+"$FC" -o "$OUT/ref_dump.x" ref_dump_driver.o Bsp_Atom_subs.o $COMMON $LINK
+rm -f *.mod
+echo "build_ref: built $OUT/Bsp_Atom_ref.x and $OUT/ref_dump.x (LAPACK: $OPENBLAS)"

@@ -1,0 +1,32 @@
+!  ref_dump_driver.f90 -- TEST INFRASTRUCTURE (oracle/_ref build only).
+!  Drives the *reference's own* routines in the order of PROGRAM BSP_ATOM_PI for
+!  KIND_PI = 0 (Bsp_Atom.f90:45-75: READ_INPUTS, GRID, SEL_LM, MATRIX_SVT, SOLVE_SYSTEM)
+!  and dumps the module state they leave behind as one unformatted stream file
+!  `ref_dump.bin`, from which tests/golden/make_golden.py extracts fixtures.
+!  Nothing here computes anything; it only reads the reference's module variables.
+      PROGRAM REF_DUMP
+      USE MOD_TYPES
+      USE MOD_GRID
+      USE MOD_BSPLINES
+      USE MOD_MATRICES
+      USE MOD_PHOTOION
+      IMPLICIT NONE
+      INTEGER :: c0, c1, c2, crate
+      CALL READ_INPUTS
+      CALL GRID
+      CALL SEL_LM
+      CALL SYSTEM_CLOCK(c0, crate)
+      CALL MATRIX_SVT
+      CALL SYSTEM_CLOCK(c1)
+      OPEN(UNIT=91, FILE='ref_dump.bin', ACCESS='STREAM', FORM='UNFORMATTED', ACTION='WRITE')
+      WRITE(91) nfun, k, ka, nkp, nointv, nbc1, nbc2, lmax
+      WRITE(91) rt(1:nkp)
+      WRITE(91) xg(1:ka), wg(1:ka)
+      WRITE(91) Aind(1:nfun,1:2)
+      WRITE(91) Sij, Tij, Vij, Uij
+      CLOSE(91)
+      CALL SOLVE_SYSTEM
+      CALL SYSTEM_CLOCK(c2)
+      WRITE(6,'(A,F12.4)') 'REF_TIME_MATRIX_SVT_S ', DBLE(c1-c0)/DBLE(crate)
+      WRITE(6,'(A,F12.4)') 'REF_TIME_SOLVE_SYSTEM_S ', DBLE(c2-c1)/DBLE(crate)
+      END PROGRAM REF_DUMP

@@ -1,0 +1,133 @@
+"""Pins the CPU oracle (oracle/bsp_oracle.c) to fixtures produced by the compiled reference.
+
+Bars: integers, knots, GL rule, Aind, S, T, V, U_l -- bit-for-bit; spectra -- LAPACK-vs-LAPACK
+noise: normwise |dE|/lambda_max <= 1e-13 everywhere, relative <= 1e-10 on linear grids.
+"""
+import numpy as np
+import pytest
+from conftest import load_golden, golden_input, SMALL_CASES, ulp_diff
+import oracle as orc
+from bspatom_amd.namelist import read_namelists
+
+
+def cfg_from_input(name):
+    nl = read_namelists(open(golden_input(name)).read())
+    kw = {}
+    kw.update(nl.get("vars_bsp", {}))
+    kw.update(nl.get("vars_tise", {}))
+    return orc.make_cfg(**kw)
+
+
+@pytest.mark.parametrize("name", SMALL_CASES + ["lin1024", "wf_fatal"])
+def test_derived_sizes_knots_rule(name):
+    g = load_golden(name)
+    c = cfg_from_input(name)
+    nfun, k, ka, nkp, nointv, nbc1, nbc2, lmax = [int(v) for v in g["sizes"]]
+    assert (c.nfun, c.k, c.ka, c.nkp, c.nointv, c.nbc1, c.nbc2, c.lmax) == (nfun, k, ka, nkp, nointv, nbc1, nbc2, lmax)
+    rt, aind, xg, wg = orc.grid(c)
+    assert np.array_equal(rt, g["rt"])
+    assert np.array_equal(xg, g["xg"]) and np.array_equal(wg, g["wg"])
+    assert np.array_equal(aind, g["aind"])
+
+
+@pytest.mark.parametrize("name", [n for n in SMALL_CASES if n not in ("lin256", "yuk256")])
+def test_matrix_svt_bit_exact(name):
+    """Reference-faithful per-pair loop (orc_matrix_svt) against the reference's dense matrices."""
+    g = load_golden(name)
+    c = cfg_from_input(name)
+    rt, aind, xg, wg = orc.grid(c)
+    S, V, T, U = orc.matrix_svt(c, rt, aind, xg, wg)
+    k = c.k
+    for d in range(k):
+        n = c.nfun - d
+        assert np.array_equal(np.diagonal(S, d), g["Sb"][d, :n]), "S diag %d" % d
+        assert np.array_equal(np.diagonal(T, d), g["Tb"][d, :n]), "T diag %d" % d
+        assert np.array_equal(np.diagonal(V, d), g["Vb"][d, :n]), "V diag %d" % d
+        for l in range(c.lmax + 1):
+            assert np.array_equal(np.diagonal(U[l], d), g["Ub"][l, d, :n]), "U l=%d diag %d" % (l, d)
+    # exact zeros outside the band, like the reference
+    mask = np.abs(np.subtract.outer(np.arange(c.nfun), np.arange(c.nfun))) >= k
+    assert not np.any(S[mask]) and not np.any(T[mask]) and not np.any(V[mask])
+
+
+@pytest.mark.parametrize("name", SMALL_CASES)
+def test_band_assembly_bit_exact(name):
+    """Interval-table band form (orc_assemble_bands): H_l = (T+U_l)+V and S, bit-for-bit."""
+    g = load_golden(name)
+    c = cfg_from_input(name)
+    rt, aind, xg, wg = orc.grid(c)
+    SB, HB = orc.assemble_bands(c, rt, aind, xg, wg)
+    assert np.array_equal(SB, g["Sb"])
+    for l in range(c.lmax + 1):
+        Href = (g["Tb"] + g["Ub"][l]) + g["Vb"]
+        assert np.array_equal(HB[l], Href), "H band l=%d" % l
+
+
+def spectrum_errors(E, Eref):
+    lam = np.max(np.abs(Eref))
+    rel = np.max(np.abs(E - Eref) / np.abs(Eref))
+    nrm = np.max(np.abs(E - Eref)) / lam
+    return rel, nrm
+
+
+@pytest.mark.parametrize("name", SMALL_CASES)
+def test_spectra_lapack(name):
+    g = load_golden(name)
+    c = cfg_from_input(name)
+    E, vec, _ = orc.solve_all(c)
+    lin = (c.kind_grid == 0)
+    for l in range(c.lmax + 1):
+        rel, nrm = spectrum_errors(E[l], g["E"][l])
+        assert nrm <= 1e-13, (name, l, nrm)
+        if lin:
+            assert rel <= 1e-10, (name, l, rel)
+
+
+@pytest.mark.parametrize("name", ["c1_exp", "c1_lin", "bc1", "ka_ra"])
+def test_spectra_plain_c_chain(name):
+    """The textbook C chain (orc_dsygv) agrees with LAPACK normwise."""
+    g = load_golden(name)
+    c = cfg_from_input(name)
+    rt, aind, xg, wg = orc.grid(c)
+    SB, HB = orc.assemble_bands(c, rt, aind, xg, wg)
+    w, v, info = orc.dsygv(orc.band_to_dense_upper(HB[0]), orc.band_to_dense_upper(SB), impl="c")
+    assert info == 0
+    rel, nrm = spectrum_errors(w, g["E"][0])
+    assert nrm <= 5e-13, (name, nrm)
+    # S-orthonormal eigenvectors
+    S = orc.band_to_dense_upper(SB); S = S + np.triu(S, 1).T
+    assert np.max(np.abs(v.T @ S @ v - np.eye(c.nfun))) < 1e-9
+
+
+@pytest.mark.parametrize("name", SMALL_CASES)
+def test_write_wf(name):
+    g = load_golden(name)
+    c = cfg_from_input(name)
+    E, vec, (rt, aind, xg, wg) = orc.solve_all(c)
+    r, u = orc.write_wf(c, rt, vec)
+    rows = g["wf_rows"]; idx = g["wf_idx"]
+    # '(2G20.10)' keeps 10 significant digits
+    assert np.allclose(r[idx], rows[:, 0], rtol=2e-10, atol=1e-300)
+    sgn = np.sign(np.dot(u[idx], rows[:, 1]))
+    scale = np.max(np.abs(rows[:, 1]))
+    assert np.max(np.abs(sgn * u[idx] - rows[:, 1])) <= 2e-8 * scale
+
+
+def test_wf_fatal_edge_case():
+    """ra=0.5, rb=40: the last WRITE_WF point rounds above rb -> interv left=1 -> BSPLVB STOP."""
+    g = load_golden("wf_fatal")
+    assert int(g["fatal"][0]) == 1 and g["E"].shape[0] == 1     # reference stopped after l = l_ini
+    c = cfg_from_input("wf_fatal")
+    rt, aind, xg, wg = orc.grid(c)
+    with pytest.raises(RuntimeError, match="BSPLVB"):
+        orc.write_wf(c, rt, np.ones(c.nfun))
+
+
+def test_rydberg_known_answers():
+    """oracle reproduces the survey's measured reference values."""
+    g = load_golden("bsp0")
+    assert abs(g["E"][0, 0] - (-0.499999999965076)) < 1e-14
+    assert abs(g["E"][1, 0] - (-0.124999999944288)) < 1e-14
+    assert abs(g["E"][2, 0] - (-0.0555555554481607)) < 1e-14
+    g = load_golden("c1_exp")
+    assert abs(g["E"][0, 0] - (-0.499999999999882)) < 1e-14
