@@ -1,0 +1,167 @@
+// bandchol.hip -- banded Cholesky of S and reduction of H(l) to standard form (dense C_l).
+//
+// Replaces DPOTRF('U') and DSYGST(1,'U') inside DSYGV (reference call matrices.f90:248):
+//   S = U^T U   (upper band, half-width b = k-1),
+//   C_l = U^-T H_l U^-1 = L^-1 H_l L^-T   with L = U^T,
+// batched over the l-channels.  S and H(l) are banded, so both steps are banded triangular
+// recurrences; C_l is dense (L^-1 is full) and is written once, column-major, ld = npad.
+//
+// Band layouts (upper): SB[d*n + i] = S(i,i+d); UB[d*n + i] = U(i,i+d); HB[(l*k+d)*n + i].
+// npad = n rounded up to a multiple of 64: rows/cols >= n of C are zero (L is extended by the
+// identity there), which keeps the later stages free of edge cases.
+#include "common.h"
+
+namespace bsp {
+
+// ---- banded Cholesky, one wavefront; LDS ring of the last b rows of U ----------------------
+__global__ __launch_bounds__(64) void band_cholesky_kernel(int n, int k, const double *__restrict__ SB,
+                                                          double *__restrict__ UB,
+                                                          double *__restrict__ rdiag, int *info)
+{
+    constexpr int BMAX = 16;
+    __shared__ double ring[BMAX + 1][BMAX + 1];   // ring[p % (b+1)][d] = U(p, p+d)
+    __shared__ int bad;
+    const int b = k - 1, t = threadIdx.x;
+    if (t == 0) bad = 0;
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        double s = 0.0;
+        const bool act = (t <= b) && (j + t < n);
+        if (act) {
+            s = SB[(size_t)t * n + j];                                   // S(j, j+t)
+            const int plo = (j + t - b > 0) ? (j + t - b) : 0;
+            for (int p = plo; p < j; ++p)
+                s -= ring[p % (b + 1)][j - p] * ring[p % (b + 1)][j + t - p];
+        }
+        // lane 0 holds the pivot
+        double piv = __shfl(s, 0);
+        if (!(piv > 0.0)) {
+            if (t == 0 && bad == 0) { bad = 1; *info = j + 1; }          // minor j+1 not PD
+        }
+        const double dj = sqrt(piv);
+        double u = (t == 0) ? dj : s / dj;
+        __syncthreads();
+        if (t <= b) {
+            if (!act) u = 0.0;
+            ring[j % (b + 1)][t] = u;
+            UB[(size_t)t * n + j] = u;
+        }
+        if (t == 0) rdiag[j] = 1.0 / dj;
+        __syncthreads();
+    }
+}
+
+// ---- standard form: two banded forward substitutions along the column index ----------------
+// PASS 1: Y(r,j) = (H(r,j) - sum_{p=1..B} L(j,j-p) Y(r,j-p)) / L(j,j)       (Y = H L^-T)
+//         stored so that Y(j,r) sits at j*ld + r, i.e. row r of Y is contiguous at r*ld.
+// PASS 2: C(r,j) = (Y(j,r) - sum_p L(j,j-p) C(r,j-p)) / L(j,j)  for j <= r   (C = (L^-1 Y)^T)
+//         stored column-major C(r,j) at j*ld + r, and mirrored C(j,r) = C(r,j).
+// One wavefront per 64 rows; a 64x64 result tile is staged in LDS for the transposed store.
+template <int B, int PASS>
+__global__ __launch_bounds__(64) void std_form_kernel(int n, int npad, int k,
+                                                     const double *__restrict__ HB,
+                                                     const double *__restrict__ UB,
+                                                     const double *__restrict__ rdiag,
+                                                     const double *__restrict__ Yin,
+                                                     double *__restrict__ out)
+{
+    __shared__ double tile[64][65];
+    __shared__ double Lc[64][B + 1];   // Lc[jj][p] = L(j, j-p), p = 1..B ; Lc[jj][0] = 1/L(j,j)
+    const int lane = threadIdx.x;
+    const int r0 = blockIdx.x * 64, r = r0 + lane;
+    const size_t ch = blockIdx.y;
+    const long ld = npad;
+    const double *H = HB + ch * (size_t)k * n;
+    const double *Y = Yin + ch * (size_t)npad * npad;
+    double *O = out + ch * (size_t)npad * npad;
+
+    double prev[B];
+#pragma unroll
+    for (int p = 0; p < B; ++p) prev[p] = 0.0;
+
+    int jbeg, jend;
+    if (PASS == 1) { jbeg = (r0 >= 64) ? (r0 - 64) : 0; jend = npad; }
+    else { jbeg = 0; jend = r0 + 64; }
+
+    for (int j0 = jbeg; j0 < jend; j0 += 64) {
+        __syncthreads();
+        for (int idx = lane; idx < 64 * (B + 1); idx += 64) {
+            const int jj = idx / (B + 1), p = idx % (B + 1), j = j0 + jj;
+            double v;
+            if (j < n) v = (p == 0) ? rdiag[j] : ((j - p >= 0) ? UB[(size_t)p * n + (j - p)] : 0.0);
+            else v = (p == 0) ? 1.0 : 0.0;
+            Lc[jj][p] = v;
+        }
+        __syncthreads();
+        double v[64];
+#pragma unroll
+        for (int jj = 0; jj < 64; ++jj) {
+            const int j = j0 + jj;
+            double acc;
+            if (PASS == 1) {
+                acc = 0.0;
+                const int d = (r > j) ? (r - j) : (j - r);
+                const int lo = (r > j) ? j : r;
+                if (d <= B && r < n && j < n) acc = H[(size_t)d * n + lo];
+            } else {
+                acc = Y[(size_t)j * ld + r];
+            }
+#pragma unroll
+            for (int p = 1; p <= B; ++p) {
+                const double yp = (p <= jj) ? v[jj - p] : prev[p - jj - 1];
+                acc -= Lc[jj][p] * yp;
+            }
+            v[jj] = acc * Lc[jj][0];
+            tile[lane][jj] = v[jj];
+            if (PASS == 2) {
+                if (j <= r) O[(size_t)j * ld + r] = v[jj];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < B; ++p) prev[p] = v[63 - p];          // prev[p] = value at j0+64-(p+1)
+        __syncthreads();
+        // transposed store: element (r0+rr, j0+lane) of the pass result goes to (r0+rr)*ld + j0+lane
+        if (PASS == 1) {
+            for (int rr = 0; rr < 64; ++rr) O[(size_t)(r0 + rr) * ld + j0 + lane] = tile[rr][lane];
+        } else {
+            for (int rr = 0; rr < 64; ++rr)
+                if (j0 + lane < r0 + rr) O[(size_t)(r0 + rr) * ld + j0 + lane] = tile[rr][lane];
+        }
+    }
+}
+
+int launch_band_cholesky(int n, int k, const double *d_SB, double *d_UB, double *d_rdiag, int *d_info,
+                         hipStream_t st)
+{
+    if (k - 1 > 16 || k < 2) return BSP_ERR_ARG;
+    hipLaunchKernelGGL(band_cholesky_kernel, dim3(1), dim3(64), 0, st, n, k, d_SB, d_UB, d_rdiag, d_info);
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
+
+template <int B>
+static int launch_std_B(int n, int npad, int k, int nl, const double *d_HB, const double *d_UB,
+                        const double *d_rdiag, double *d_Y, double *d_C, hipStream_t st)
+{
+    dim3 grid(npad / 64, nl), block(64);
+    hipLaunchKernelGGL((std_form_kernel<B, 1>), grid, block, 0, st, n, npad, k, d_HB, d_UB, d_rdiag,
+                       (const double *)d_Y, d_Y);
+    hipLaunchKernelGGL((std_form_kernel<B, 2>), grid, block, 0, st, n, npad, k, d_HB, d_UB, d_rdiag,
+                       (const double *)d_Y, d_C);
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
+
+int launch_standard_form(int n, int npad, int k, int nl, const double *d_HB, const double *d_UB,
+                         const double *d_rdiag, double *d_Y, double *d_C, hipStream_t st)
+{
+    switch (k - 1) {
+#define CASE_B(B) case B: return launch_std_B<B>(n, npad, k, nl, d_HB, d_UB, d_rdiag, d_Y, d_C, st);
+        CASE_B(1) CASE_B(2) CASE_B(3) CASE_B(4) CASE_B(5) CASE_B(6) CASE_B(7) CASE_B(8)
+        CASE_B(9) CASE_B(10) CASE_B(11) CASE_B(12) CASE_B(13) CASE_B(14) CASE_B(15)
+#undef CASE_B
+    default: return BSP_ERR_ARG;
+    }
+}
+
+}  // namespace bsp

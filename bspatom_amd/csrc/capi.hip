@@ -1,0 +1,424 @@
+// capi.hip -- the C ABI of libbspatom (include/bspatom.h): problem handle, the batched solve
+// pipeline and the stage-level entry points.  One HIP stream per problem; every stage of a solve
+// is enqueued on it back-to-back (no host synchronisation between stages) and timed with events.
+#include <cstring>
+#include <new>
+#include <vector>
+#include "common.h"
+#include "host_setup.h"
+
+using namespace bsp;
+
+struct bspatom_problem {
+    HostSetup hs;
+    int device;
+    int npad;
+    hipStream_t st;
+    // device: set-up tables
+    double *d_rt = nullptr, *d_aind = nullptr, *d_xg = nullptr, *d_wg = nullptr, *d_vpot = nullptr, *d_bl = nullptr;
+    double *d_ptab = nullptr; int *d_left = nullptr; int *d_status = nullptr;
+    bool ptab_ready = false;
+    // device: per-solve buffers (sized for cap_nl channels)
+    int cap_nl = 0;
+    double *d_SB = nullptr, *d_HB = nullptr, *d_UB = nullptr, *d_rdiag = nullptr;
+    double *d_Y = nullptr, *d_C = nullptr, *d_AB = nullptr, *d_d = nullptr, *d_e = nullptr, *d_E = nullptr;
+    void *d_work = nullptr;
+    int *d_info = nullptr;
+    // eigenvector / wave-function scratch
+    double *d_vwork = nullptr, *d_vec = nullptr, *d_wfr = nullptr, *d_wfu = nullptr, *d_Esel = nullptr;
+    int *d_chan = nullptr;
+    int wf_cap = 0;
+    // last solve
+    int last_l0 = 0, last_nl = 0;
+    hipEvent_t ev[7];
+    double ms[6] = {0, 0, 0, 0, 0, 0};
+};
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+extern "C" void bspatom_input_defaults(bspatom_input *in) { input_defaults(in); }
+
+extern "C" int bspatom_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static void free_solve_buffers(bspatom_problem *p)
+{
+    hipFree(p->d_SB); hipFree(p->d_HB); hipFree(p->d_UB); hipFree(p->d_rdiag); hipFree(p->d_Y);
+    hipFree(p->d_C); hipFree(p->d_AB); hipFree(p->d_d); hipFree(p->d_e); hipFree(p->d_E); hipFree(p->d_work);
+    p->d_SB = p->d_HB = p->d_UB = p->d_rdiag = p->d_Y = p->d_C = p->d_AB = p->d_d = p->d_e = p->d_E = nullptr;
+    p->d_work = nullptr;
+    p->cap_nl = 0;
+}
+
+extern "C" void bspatom_problem_destroy(bspatom_problem *p)
+{
+    if (!p) return;
+    hipSetDevice(p->device);
+    free_solve_buffers(p);
+    hipFree(p->d_rt); hipFree(p->d_aind); hipFree(p->d_xg); hipFree(p->d_wg); hipFree(p->d_vpot);
+    hipFree(p->d_bl); hipFree(p->d_ptab); hipFree(p->d_left); hipFree(p->d_status); hipFree(p->d_info);
+    hipFree(p->d_vwork); hipFree(p->d_vec); hipFree(p->d_wfr); hipFree(p->d_wfu); hipFree(p->d_Esel); hipFree(p->d_chan);
+    for (auto &e : p->ev) hipEventDestroy(e);
+    hipStreamDestroy(p->st);
+    delete p;
+}
+
+template <class T>
+static int upload(T **dst, const T *src, size_t count)
+{
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(dst), count * sizeof(T)));
+    BSP_HIP(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return BSP_OK;
+}
+
+extern "C" int bspatom_problem_create(const bspatom_input *in, int device, bspatom_problem **out)
+{
+    if (!in || !out) return BSP_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        fprintf(stderr, "bspatom: no HIP device %d (libbspatom has no CPU path)\n", device);
+        return BSP_ERR_NOGPU;
+    }
+    bspatom_problem *p = new (std::nothrow) bspatom_problem;
+    if (!p) return BSP_ERR_ARG;
+    if (derive(*in, &p->hs) != 0) { delete p; return BSP_ERR_ARG; }
+    build_grid(&p->hs);
+    build_vpot(&p->hs);
+    p->device = device;
+    p->npad = round_up(p->hs.nfun, 64);
+    BSP_HIP(hipSetDevice(device));
+    BSP_HIP(hipStreamCreate(&p->st));
+    for (auto &e : p->ev) BSP_HIP(hipEventCreate(&e));
+    const HostSetup &h = p->hs;
+    int rc;
+    if ((rc = upload(&p->d_rt, h.rt.data(), h.rt.size()))) return rc;
+    if ((rc = upload(&p->d_aind, h.aind.data(), h.aind.size()))) return rc;
+    if ((rc = upload(&p->d_xg, h.xg.data(), h.xg.size()))) return rc;
+    if ((rc = upload(&p->d_wg, h.wg.data(), h.wg.size()))) return rc;
+    if ((rc = upload(&p->d_vpot, h.vpot.data(), h.vpot.size()))) return rc;
+    if ((rc = upload(&p->d_bl, h.bl, (size_t)4))) return rc;
+    const size_t npt = (size_t)(h.nkp - 1) * h.ka;
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_ptab), npt * (2 * h.k + 3) * sizeof(double)));
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_left), npt * sizeof(int)));
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_status), sizeof(int)));
+    BSP_HIP(hipMemset(p->d_status, 0, sizeof(int)));
+    *out = p;
+    return BSP_OK;
+}
+
+extern "C" int bspatom_problem_sizes(const bspatom_problem *p, bspatom_sizes *s)
+{
+    if (!p || !s) return BSP_ERR_ARG;
+    const HostSetup &h = p->hs;
+    s->nfun = h.nfun; s->k = h.k; s->ka = h.ka; s->nkp = h.nkp; s->nointv = h.nointv;
+    s->nbc1 = h.nbc1; s->nbc2 = h.nbc2; s->lmax = h.lmax; s->nintv_exp = h.nintv_exp;
+    s->nintv_lin = h.nintv_lin; s->npad = p->npad;
+    return BSP_OK;
+}
+
+extern "C" int bspatom_problem_grid(const bspatom_problem *p, double *rt, double *aind, double *xg, double *wg)
+{
+    if (!p) return BSP_ERR_ARG;
+    const HostSetup &h = p->hs;
+    if (rt) memcpy(rt, h.rt.data(), h.rt.size() * sizeof(double));
+    if (aind) memcpy(aind, h.aind.data(), h.aind.size() * sizeof(double));
+    if (xg) memcpy(xg, h.xg.data(), h.xg.size() * sizeof(double));
+    if (wg) memcpy(wg, h.wg.data(), h.wg.size() * sizeof(double));
+    return BSP_OK;
+}
+
+static int ensure_capacity(bspatom_problem *p, int nl)
+{
+    if (nl <= p->cap_nl) return BSP_OK;
+    free_solve_buffers(p);
+    const HostSetup &h = p->hs;
+    const size_t n = h.nfun, k = h.k, np = p->npad, b = nl;
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_SB), k * n * sizeof(double)));
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_HB), b * k * n * sizeof(double)));
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_UB), k * n * sizeof(double)));
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_rdiag), n * sizeof(double)));
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_Y), b * np * np * sizeof(double)));
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_C), b * np * np * sizeof(double)));
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_AB), b * np * 128 * sizeof(double)));
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_d), b * np * sizeof(double)));
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_e), b * np * sizeof(double)));
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_E), b * n * sizeof(double)));
+    BSP_HIP(hipMalloc(&p->d_work, sy2sb_work_bytes((int)np, 64, nl)));
+    if (!p->d_info) BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_info), sizeof(int)));
+    p->cap_nl = nl;
+    return BSP_OK;
+}
+
+// enqueue point table (once) + band assembly for channels l0..l0+nl-1
+static int enqueue_assemble(bspatom_problem *p, int l0, int nl)
+{
+    const HostSetup &h = p->hs;
+    int rc;
+    if (!p->ptab_ready) {
+        if ((rc = launch_point_table(h.nkp, h.k, h.ka, h.nfun, p->d_rt, p->d_aind, p->d_xg, p->d_wg, p->d_vpot,
+                                     p->d_ptab, p->d_left, p->d_status, p->st))) return rc;
+        p->ptab_ready = true;
+    }
+    return launch_assemble_bands(h.nfun, h.k, h.ka, h.nkp, h.in.kind_pot, p->d_bl, l0, nl, p->d_ptab, p->d_left,
+                                 p->d_SB, p->d_HB, p->st);
+}
+
+static int check_status(bspatom_problem *p)
+{
+    int st = 0;
+    BSP_HIP(hipMemcpy(&st, p->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    return st;
+}
+
+extern "C" int bspatom_assemble(bspatom_problem *p, int l0, int nl, double *SB, double *HB)
+{
+    if (!p || nl <= 0 || l0 < 0) return BSP_ERR_ARG;
+    BSP_HIP(hipSetDevice(p->device));
+    int rc;
+    if ((rc = ensure_capacity(p, nl))) return rc;
+    if ((rc = enqueue_assemble(p, l0, nl))) return rc;
+    BSP_HIP(hipStreamSynchronize(p->st));
+    if ((rc = check_status(p))) return rc;
+    const size_t kn = (size_t)p->hs.k * p->hs.nfun;
+    if (SB) BSP_HIP(hipMemcpy(SB, p->d_SB, kn * sizeof(double), hipMemcpyDeviceToHost));
+    if (HB) BSP_HIP(hipMemcpy(HB, p->d_HB, kn * nl * sizeof(double), hipMemcpyDeviceToHost));
+    return BSP_OK;
+}
+
+namespace bsp {
+int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const double *d_HB, const PipeBufs &b,
+                     double *d_Eout, hipStream_t st, hipEvent_t *ev)
+{
+    int rc;
+    if ((rc = launch_band_cholesky(n, k, d_SB, b.UB, b.rdiag, b.info, st))) return rc;
+    if ((rc = launch_standard_form(n, npad, k, nl, d_HB, b.UB, b.rdiag, b.Y, b.C, st))) return rc;
+    if (ev) BSP_HIP(hipEventRecord(ev[1], st));
+    Sy2sbWork w;
+    sy2sb_carve(b.work, npad, 64, nl, &w);
+    if ((rc = sy2sb_run(npad, 64, nl, b.C, w, st))) return rc;
+    if ((rc = launch_extract_band(npad, 64, nl, b.C, b.AB, st))) return rc;
+    if (ev) BSP_HIP(hipEventRecord(ev[2], st));
+    if ((rc = launch_sb2st(n, npad, 64, nl, b.AB, b.d, b.e, st))) return rc;
+    if (ev) BSP_HIP(hipEventRecord(ev[3], st));
+    if ((rc = launch_bisect(n, npad, nl, b.d, b.e, d_Eout, n, st))) return rc;
+    if (ev) BSP_HIP(hipEventRecord(ev[4], st));
+    return BSP_OK;
+}
+}  // namespace bsp
+
+static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, double *E_host, int32_t *info)
+{
+    if (!p || nl <= 0 || l0 < 0) return BSP_ERR_ARG;
+    BSP_HIP(hipSetDevice(p->device));
+    const HostSetup &h = p->hs;
+    const int n = h.nfun, np = p->npad;
+    int rc;
+    if ((rc = ensure_capacity(p, nl))) return rc;
+    BSP_HIP(hipMemsetAsync(p->d_info, 0, sizeof(int), p->st));
+    BSP_HIP(hipEventRecord(p->ev[0], p->st));
+    if ((rc = enqueue_assemble(p, l0, nl))) return rc;
+    BSP_HIP(hipEventRecord(p->ev[1], p->st));
+    PipeBufs pb{p->d_UB, p->d_rdiag, p->d_Y, p->d_C, p->d_AB, p->d_d, p->d_e, p->d_work, p->d_info};
+    double *Eout = E_dev_out ? E_dev_out : p->d_E;
+    if ((rc = pipeline_enqueue(n, np, h.k, nl, p->d_SB, p->d_HB, pb, Eout, p->st, &p->ev[1]))) return rc;
+    if (E_dev_out)   // keep a copy for bspatom_eigvec
+        BSP_HIP(hipMemcpyAsync(p->d_E, E_dev_out, (size_t)nl * n * sizeof(double), hipMemcpyDeviceToDevice, p->st));
+    BSP_HIP(hipStreamSynchronize(p->st));
+    for (int i = 0; i < 5; ++i) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]);
+        p->ms[i] = ms;
+    }
+    float tot = 0.f;
+    hipEventElapsedTime(&tot, p->ev[0], p->ev[5]);
+    p->ms[5] = tot;
+    if ((rc = check_status(p))) return rc;
+    int cinfo = 0;
+    BSP_HIP(hipMemcpy(&cinfo, p->d_info, sizeof(int), hipMemcpyDeviceToHost));
+    if (info)
+        for (int l = 0; l < nl; ++l) info[l] = cinfo ? n + cinfo : 0;       // DSYGV: n+i, B not PD
+    if (E_host) BSP_HIP(hipMemcpy(E_host, p->d_E, (size_t)nl * n * sizeof(double), hipMemcpyDeviceToHost));
+    p->last_l0 = l0; p->last_nl = nl;
+    return BSP_OK;
+}
+
+extern "C" int bspatom_solve(bspatom_problem *p, int l0, int nl, double *E, int32_t *info)
+{
+    return solve_impl(p, l0, nl, nullptr, E, info);
+}
+
+extern "C" int bspatom_solve_dev(bspatom_problem *p, int l0, int nl, double *E_dev, int32_t *info)
+{
+    if (!E_dev) return BSP_ERR_ARG;
+    return solve_impl(p, l0, nl, E_dev, nullptr, info);
+}
+
+extern "C" int bspatom_last_timing(const bspatom_problem *p, double ms[6])
+{
+    if (!p || !ms) return BSP_ERR_ARG;
+    for (int i = 0; i < 6; ++i) ms[i] = p->ms[i];
+    return BSP_OK;
+}
+
+extern "C" int bspatom_eigvec(bspatom_problem *p, int l, int n0, double *c)
+{
+    if (!p || !c) return BSP_ERR_ARG;
+    const HostSetup &h = p->hs;
+    const int n = h.nfun;
+    if (l < p->last_l0 || l >= p->last_l0 + p->last_nl || n0 < 1 || n0 > n) return BSP_ERR_ARG;
+    BSP_HIP(hipSetDevice(p->device));
+    if (!p->d_vwork) {
+        BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_vwork), invit_work_doubles(n, h.k) * sizeof(double)));
+        BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_vec), (size_t)n * sizeof(double)));
+        BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_chan), sizeof(int)));
+        BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_Esel), sizeof(double)));
+    }
+    const int ch = l - p->last_l0;
+    BSP_HIP(hipMemcpyAsync(p->d_chan, &ch, sizeof(int), hipMemcpyHostToDevice, p->st));
+    BSP_HIP(hipMemcpyAsync(p->d_Esel, p->d_E + (size_t)ch * n + (n0 - 1), sizeof(double), hipMemcpyDeviceToDevice, p->st));
+    BSP_HIP(hipMemsetAsync(p->d_info, 0, sizeof(int), p->st));
+    int rc;
+    if ((rc = launch_inverse_iteration(n, h.k, 1, p->d_SB, p->d_HB, p->d_chan, p->d_Esel, p->d_vwork, p->d_vec,
+                                       p->d_info, p->st))) return rc;
+    BSP_HIP(hipMemcpyAsync(c, p->d_vec, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, p->st));
+    BSP_HIP(hipStreamSynchronize(p->st));
+    return BSP_OK;
+}
+
+extern "C" int bspatom_write_wf(bspatom_problem *p, const double *c, int npts, double *r, double *u)
+{
+    if (!p || !c || !r || !u || npts < 1) return BSP_ERR_ARG;
+    const HostSetup &h = p->hs;
+    BSP_HIP(hipSetDevice(p->device));
+    if (p->wf_cap < npts + 1) {
+        hipFree(p->d_wfr); hipFree(p->d_wfu);
+        BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_wfr), (size_t)(npts + 1) * sizeof(double)));
+        BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_wfu), (size_t)(npts + 1) * sizeof(double)));
+        p->wf_cap = npts + 1;
+    }
+    double *d_c = nullptr;
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&d_c), (size_t)h.nfun * sizeof(double)));
+    hipMemcpyAsync(d_c, c, (size_t)h.nfun * sizeof(double), hipMemcpyHostToDevice, p->st);
+    hipMemsetAsync(p->d_status, 0, sizeof(int), p->st);
+    int rc = launch_wf_tabulate(h.nkp, h.k, h.nfun, p->d_rt, d_c, h.in.ra, h.in.rb, npts, p->d_wfr, p->d_wfu,
+                                p->d_status, p->st);
+    hipError_t e = hipStreamSynchronize(p->st);
+    hipFree(d_c);
+    if (rc) return rc;
+    BSP_HIP(e);
+    if ((rc = check_status(p))) { hipMemset(p->d_status, 0, sizeof(int)); return rc; }
+    BSP_HIP(hipMemcpy(r, p->d_wfr, (size_t)(npts + 1) * sizeof(double), hipMemcpyDeviceToHost));
+    BSP_HIP(hipMemcpy(u, p->d_wfu, (size_t)(npts + 1) * sizeof(double), hipMemcpyDeviceToHost));
+    return BSP_OK;
+}
+
+// ---- stage-level entry points ----------------------------------------------------------------
+struct DevBuf {
+    double *p = nullptr;
+    ~DevBuf() { hipFree(p); }
+    int alloc(size_t n) { BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p), (n ? n : 1) * sizeof(double))); return BSP_OK; }
+    int put(const double *h, size_t n) { int rc = alloc(n); if (rc) return rc; BSP_HIP(hipMemcpy(p, h, n * sizeof(double), hipMemcpyHostToDevice)); return BSP_OK; }
+    int get(double *h, size_t n) { BSP_HIP(hipMemcpy(h, p, n * sizeof(double), hipMemcpyDeviceToHost)); return BSP_OK; }
+};
+
+static int need_gpu()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        fprintf(stderr, "bspatom: no HIP device (libbspatom has no CPU path)\n");
+        return BSP_ERR_NOGPU;
+    }
+    return BSP_OK;
+}
+
+extern "C" int bspatom_stage_gemm(int M, int N, int K, int batch, const double *A, long sAm, long sAk, long bA,
+                                  long lenA, const double *B, long sBk, long sBn, long bB, long lenB, double *C,
+                                  long sCm, long sCn, long bC, long lenC, double alpha, double beta)
+{
+    int rc;
+    if ((rc = need_gpu())) return rc;
+    DevBuf dA, dB, dC;
+    if ((rc = dA.put(A, lenA)) || (rc = dB.put(B, lenB)) || (rc = dC.put(C, lenC))) return rc;
+    GemmDesc g{};
+    g.M = M; g.N = N; g.K = K; g.batch = batch;
+    g.A = dA.p; g.sAm = sAm; g.sAk = sAk; g.bA = bA;
+    g.B = dB.p; g.sBk = sBk; g.sBn = sBn; g.bB = bB;
+    g.C = dC.p; g.sCm = sCm; g.sCn = sCn; g.bC = bC;
+    g.alpha = alpha; g.beta = beta; g.lower_only = 0;
+    if ((rc = gemm_f64(g, 0))) return rc;
+    BSP_HIP(hipDeviceSynchronize());
+    return dC.get(C, lenC);
+}
+
+extern "C" int bspatom_stage_standard_form(int n, int k, int nl, const double *SB, const double *HB, double *UB,
+                                           double *C, int32_t *info)
+{
+    int rc;
+    if ((rc = need_gpu())) return rc;
+    const int np = round_up(n, 64);
+    DevBuf dSB, dHB, dUB, dr, dY, dC;
+    int *dinfo = nullptr;
+    if ((rc = dSB.put(SB, (size_t)k * n)) || (rc = dHB.put(HB, (size_t)nl * k * n)) || (rc = dUB.alloc((size_t)k * n)) ||
+        (rc = dr.alloc(n)) || (rc = dY.alloc((size_t)nl * np * np)) || (rc = dC.alloc((size_t)nl * np * np))) return rc;
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&dinfo), sizeof(int)));
+    BSP_HIP(hipMemset(dinfo, 0, sizeof(int)));
+    BSP_HIP(hipMemset(dY.p, 0, (size_t)nl * np * np * sizeof(double)));
+    if ((rc = launch_band_cholesky(n, k, dSB.p, dUB.p, dr.p, dinfo, 0))) return rc;
+    if ((rc = launch_standard_form(n, np, k, nl, dHB.p, dUB.p, dr.p, dY.p, dC.p, 0))) return rc;
+    BSP_HIP(hipDeviceSynchronize());
+    int hi = 0;
+    BSP_HIP(hipMemcpy(&hi, dinfo, sizeof(int), hipMemcpyDeviceToHost));
+    hipFree(dinfo);
+    if (info) *info = hi;
+    if (UB && (rc = dUB.get(UB, (size_t)k * n))) return rc;
+    return dC.get(C, (size_t)nl * np * np);
+}
+
+extern "C" int bspatom_stage_sy2sb(int npad, int batch, const double *A, double *AB)
+{
+    int rc;
+    if ((rc = need_gpu())) return rc;
+    if (npad % 64) return BSP_ERR_ARG;
+    DevBuf dA, dAB;
+    if ((rc = dA.put(A, (size_t)batch * npad * npad)) || (rc = dAB.alloc((size_t)batch * npad * 128))) return rc;
+    void *work = nullptr;
+    BSP_HIP(hipMalloc(&work, sy2sb_work_bytes(npad, 64, batch)));
+    Sy2sbWork w;
+    sy2sb_carve(work, npad, 64, batch, &w);
+    rc = sy2sb_run(npad, 64, batch, dA.p, w, 0);
+    if (!rc) rc = launch_extract_band(npad, 64, batch, dA.p, dAB.p, 0);
+    hipError_t e = hipDeviceSynchronize();
+    hipFree(work);
+    if (rc) return rc;
+    BSP_HIP(e);
+    return dAB.get(AB, (size_t)batch * npad * 128);
+}
+
+extern "C" int bspatom_stage_sb2st(int n, int npad, int batch, const double *AB, double *d, double *e)
+{
+    int rc;
+    if ((rc = need_gpu())) return rc;
+    DevBuf dAB, dd, de;
+    if ((rc = dAB.put(AB, (size_t)batch * npad * 128)) || (rc = dd.alloc((size_t)batch * npad)) ||
+        (rc = de.alloc((size_t)batch * npad))) return rc;
+    if ((rc = launch_sb2st(n, npad, 64, batch, dAB.p, dd.p, de.p, 0))) return rc;
+    BSP_HIP(hipDeviceSynchronize());
+    if ((rc = dd.get(d, (size_t)batch * npad))) return rc;
+    return de.get(e, (size_t)batch * npad);
+}
+
+extern "C" int bspatom_stage_bisect(int n, int batch, const double *d, const double *e, double *w)
+{
+    int rc;
+    if ((rc = need_gpu())) return rc;
+    DevBuf dd, de, dw;
+    if ((rc = dd.put(d, (size_t)batch * n)) || (rc = de.put(e, (size_t)batch * n)) || (rc = dw.alloc((size_t)batch * n))) return rc;
+    if ((rc = launch_bisect(n, n, batch, dd.p, de.p, dw.p, n, 0))) return rc;
+    BSP_HIP(hipDeviceSynchronize());
+    return dw.get(w, (size_t)batch * n);
+}

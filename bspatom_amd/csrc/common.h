@@ -1,0 +1,96 @@
+// common.h -- shared declarations of libbspatom (MI355X / gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+// status codes of the C ABI (include/bspatom.h)
+#define BSP_OK 0
+#define BSP_ERR_HIP (-1)       // HIP runtime error (message on stderr)
+#define BSP_ERR_ARG (-2)       // invalid argument
+#define BSP_ERR_BSPLVB (-3)    // 'FATAL ERROR - BSPLVB' (reference bsplvb.f90:30-34)
+#define BSP_ERR_NOGPU (-4)     // no gfx950 device visible
+#define BSP_ERR_UNSUPPORTED (-5)
+
+#define BSP_HIP(x)                                                                          \
+    do {                                                                                    \
+        hipError_t e_ = (x);                                                                \
+        if (e_ != hipSuccess) {                                                             \
+            fprintf(stderr, "bspatom: HIP error '%s' at %s:%d\n", hipGetErrorString(e_),    \
+                    __FILE__, __LINE__);                                                    \
+            return BSP_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+namespace bsp {
+
+// ---- batched fp64 MFMA GEMM: C[b] = alpha * A[b] * B[b] + beta * C[b] ----------------------
+// Element (i,k) of A[b] is at A + b*bA + i*sAm + k*sAk (one of sAm, sAk must be 1), likewise
+// B(k,j) at B + b*bB + k*sBk + j*sBn and C(i,j) at C + b*bC + i*sCm + j*sCn.
+struct GemmDesc {
+    int M, N, K, batch;
+    const double *A; long sAm, sAk, bA;
+    const double *B; long sBk, sBn, bB;
+    double *C; long sCm, sCn, bC;
+    double alpha, beta;
+    int lower_only;   // 1: C is square/symmetric, compute only tiles touching i >= j (col-major C)
+};
+int gemm_f64(const GemmDesc &g, hipStream_t st);
+
+// ---- stage kernels (launchers) -------------------------------------------------------------
+// assemble.hip
+int launch_point_table(int nkp, int k, int ka, int nfun, const double *d_rt, const double *d_aind,
+                       const double *d_xg, const double *d_wg, const double *d_vpot, double *d_ptab,
+                       int *d_left, int *d_status, hipStream_t st);
+int launch_assemble_bands(int nfun, int k, int ka, int nkp, int kind_pot, const double *d_bl, int l0,
+                          int nl, const double *d_ptab, const int *d_left, double *d_SB, double *d_HB,
+                          hipStream_t st);
+// bandchol.hip
+int launch_band_cholesky(int n, int k, const double *d_SB, double *d_UB, double *d_rdiag, int *d_info,
+                         hipStream_t st);
+int launch_standard_form(int n, int npad, int k, int nl, const double *d_HB, const double *d_UB,
+                         const double *d_rdiag, double *d_Y, double *d_C, hipStream_t st);
+// sy2sb.hip
+struct Sy2sbWork {
+    double *buf;    // [batch][npad][3*nb]  : [V | Z | V]
+    double *W;      // [batch][npad][nb]
+    double *G;      // [batch][nb][nb]
+    double *T;      // [batch][nb][nb]
+    double *Kmat;   // [batch][nb][nb]
+    double *tau;    // [batch][nb]
+};
+size_t sy2sb_work_bytes(int npad, int nb, int batch);
+void sy2sb_carve(void *base, int npad, int nb, int batch, Sy2sbWork *w);
+int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipStream_t st);
+int launch_extract_band(int npad, int nb, int batch, const double *d_A, double *d_AB, hipStream_t st);
+// sb2st.hip
+int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, double *d_e,
+                 hipStream_t st);
+// tridiag.hip
+int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_e, double *d_w,
+                  long ldw, hipStream_t st);
+// eigvec.hip
+// vector iv: channel chan[iv] of HB (HB + chan*k*n), eigenvalue E[iv]; work: nvec*invit_work_doubles
+int launch_inverse_iteration(int n, int k, int nvec, const double *d_SB, const double *d_HB,
+                             const int *d_chan, const double *d_E, double *d_work, double *d_vec,
+                             int *d_info, hipStream_t st);
+size_t invit_work_doubles(int n, int k);
+int launch_wf_tabulate(int nkp, int k, int n, const double *d_rt, const double *d_c, double ra,
+                       double rb, int npts, double *d_r, double *d_u, int *d_status, hipStream_t st);
+
+// capi.hip: enqueue Cholesky -> standard form -> sy2sb -> sb2st -> bisection on `st` for nl channels
+// whose upper bands are already in d_SB / d_HB.  ev (optional): 5 events recorded at the stage
+// boundaries [after chol+std, after sy2sb, after sb2st, after bisect] starting from ev[0] = begin.
+struct PipeBufs {
+    double *UB, *rdiag, *Y, *C, *AB, *d, *e;
+    void *work;
+    int *info;
+};
+size_t pipe_bytes_per_channel(int npad);
+int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const double *d_HB,
+                     const PipeBufs &b, double *d_Eout, hipStream_t st, hipEvent_t *ev);
+
+}  // namespace bsp

@@ -1,0 +1,370 @@
+// sy2sb.hip -- stage 1 of the two-stage tridiagonalisation: dense symmetric -> band (half-width 64).
+//
+// Replaces the first half of LAPACK DSYTRD inside DSYEV/DSYGV (reference call matrices.f90:248).
+// Batched over l-channels: every launch covers all channels (grid.z / grid.x = channel).
+//
+// Per panel p (columns c0 = p*NB .. c0+NB-1, rows r0 = c0+NB .. npad-1, m = npad - r0):
+//   1. panel_qr_kernel : Householder QR of P = A[r0:, c0:c0+NB]  ->  R (left in A), explicit V
+//                        (unit lower trapezoid, written twice into buf = [V | . | V]) and tau
+//   2. G = V^T V (MFMA GEMM), form_T_kernel: T from G and tau (dlarft forward/columnwise)
+//   3. W = V T                                   (MFMA GEMM)
+//   4. Y = A22 W              -> buf middle slot  (MFMA GEMM, the SYMM-shaped half of the flops)
+//   5. K = W^T Y ; Z = Y - 1/2 V K (in place)    (MFMA GEMMs)
+//   6. A22 -= [V Z] [Z V]^T                      (MFMA GEMM, the SYR2K-shaped half of the flops)
+// with A22 = A[r0:, r0:] kept in full symmetric storage (column-major, ld = npad).
+//
+// panel_qr_kernel: ONE workgroup (512 threads) per channel.  The m x 64 panel is processed in
+// sub-panels of SW = 4 columns held entirely in registers (thread t owns rows t, t+512, ...;
+// RPT rows per thread), so a column step costs two workgroup reductions and no memory traffic;
+// after a sub-panel is factored its block reflector (I - V_s T_s^T V_s^T) is applied to the
+// remaining panel columns CW = 4 at a time, streaming them through registers.
+#include "common.h"
+
+namespace bsp {
+
+constexpr int NB = 64;     // band half-width after stage 1
+constexpr int PQ_THREADS = 512;
+constexpr int SW = 4, CW = 4;
+
+template <int NV>
+__device__ __forceinline__ void block_allreduce(double (&v)[NV], double *red, int lane, int wave)
+{
+    constexpr int NW = PQ_THREADS / 64;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += red[w * NV + i];
+        v[i] = s;
+    }
+    __syncthreads();
+}
+
+template <int RPT>
+__global__ __launch_bounds__(PQ_THREADS) void panel_qr_kernel(int npad, int r0, int c0, double *Aall,
+                                                             double *bufall, double *tauall)
+{
+    __shared__ double red[(PQ_THREADS / 64) * SW * CW];
+    __shared__ double sh_alpha;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t ch = blockIdx.x;
+    const long ld = npad;
+    const int m = npad - r0;
+    double *P = Aall + ch * (size_t)npad * npad + (size_t)c0 * ld + r0;   // P(i,j) = P[i + j*ld]
+    double *buf = bufall + ch * (size_t)npad * 3 * NB;                    // buf(i,c) = buf[i + c*npad]
+    double *tau_g = tauall + ch * NB;
+
+    for (int js = 0; js < NB; js += SW) {
+        double a[RPT][SW];
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int i = tid + PQ_THREADS * q;
+#pragma unroll
+            for (int jj = 0; jj < SW; ++jj) a[q][jj] = (i < m) ? P[i + (size_t)(js + jj) * ld] : 0.0;
+        }
+        double taus[SW];
+        // ---- factor the sub-panel ----
+#pragma unroll
+        for (int jj = 0; jj < SW; ++jj) {
+            const int j = js + jj;                       // pivot row (panel-relative)
+            double part[1] = {0.0};
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int i = tid + PQ_THREADS * q;
+                if (i > j && i < m) part[0] += a[q][jj] * a[q][jj];
+                if (i == j) sh_alpha = a[q][jj];
+            }
+            block_allreduce<1>(part, red, lane, wave);   // barriers inside publish sh_alpha too
+            const double alpha = sh_alpha, sigma = part[0];
+            double beta, tau, scale;
+            if (j >= m - 1 || !(alpha * alpha + sigma > 1e-280) || sigma == 0.0) {
+                // nothing (numerically) below the pivot: H = I; tiny entries are dropped
+                beta = alpha; tau = 0.0; scale = 0.0;
+            } else {
+                const double nrm = sqrt(alpha * alpha + sigma);
+                beta = (alpha >= 0.0) ? -nrm : nrm;
+                tau = (beta - alpha) / beta;
+                scale = 1.0 / (alpha - beta);
+            }
+            taus[jj] = tau;
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int i = tid + PQ_THREADS * q;
+                if (i > j) a[q][jj] *= scale;            // v_i
+                if (i == j) a[q][jj] = beta;             // R(j,j)
+            }
+            // apply H_j to the remaining columns of the sub-panel
+            if (jj < SW - 1) {
+                double w[SW - 1];
+#pragma unroll
+                for (int c = 0; c < SW - 1; ++c) w[c] = 0.0;
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) {
+                    const int i = tid + PQ_THREADS * q;
+                    const double vv = (i > j) ? a[q][jj] : ((i == j) ? 1.0 : 0.0);
+#pragma unroll
+                    for (int c = jj + 1; c < SW; ++c) w[c - 1] += vv * a[q][c];
+                }
+                block_allreduce<SW - 1>(w, red, lane, wave);
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) {
+                    const int i = tid + PQ_THREADS * q;
+                    const double vv = (i > j) ? a[q][jj] : ((i == j) ? 1.0 : 0.0);
+#pragma unroll
+                    for (int c = jj + 1; c < SW; ++c) a[q][c] -= tau * vv * w[c - 1];
+                }
+            }
+        }
+        // ---- T_s of the sub-panel from G_s = V_s^T V_s ----
+        double g[SW * SW];
+#pragma unroll
+        for (int x = 0; x < SW * SW; ++x) g[x] = 0.0;
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int i = tid + PQ_THREADS * q;
+            double vv[SW];
+#pragma unroll
+            for (int c = 0; c < SW; ++c) vv[c] = (i > js + c) ? a[q][c] : ((i == js + c) ? 1.0 : 0.0);
+#pragma unroll
+            for (int x = 0; x < SW; ++x)
+#pragma unroll
+                for (int y = x + 1; y < SW; ++y) g[x * SW + y] += vv[x] * vv[y];
+        }
+        block_allreduce<SW * SW>(g, red, lane, wave);
+        double Ts[SW][SW];
+#pragma unroll
+        for (int x = 0; x < SW; ++x)
+#pragma unroll
+            for (int y = 0; y < SW; ++y) Ts[x][y] = 0.0;
+#pragma unroll
+        for (int y = 0; y < SW; ++y) {
+            Ts[y][y] = taus[y];
+#pragma unroll
+            for (int x = 0; x < y; ++x) {
+                double s = 0.0;
+#pragma unroll
+                for (int z = x; z < y; ++z) s += Ts[x][z] * g[z * SW + y];
+                Ts[x][y] = -taus[y] * s;
+            }
+        }
+        // ---- write R / zeros back to the panel, V (explicit) to buf, tau ----
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int i = tid + PQ_THREADS * q;
+            if (i < m) {
+#pragma unroll
+                for (int jj = 0; jj < SW; ++jj) {
+                    const int j = js + jj;
+                    const double vv = (i > j) ? a[q][jj] : ((i == j) ? 1.0 : 0.0);
+                    P[i + (size_t)j * ld] = (i <= j) ? a[q][jj] : 0.0;
+                    buf[i + (size_t)j * npad] = vv;
+                    buf[i + (size_t)(2 * NB + j) * npad] = vv;
+                }
+            }
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int jj = 0; jj < SW; ++jj) tau_g[js + jj] = taus[jj];
+        }
+        // ---- apply (I - V_s T_s^T V_s^T) to the remaining panel columns, CW at a time ----
+        for (int cs = js + SW; cs < NB; cs += CW) {
+            // pass 1: wp = V_s^T X (X streamed, not kept: registers hold V_s only)
+            double wp[SW * CW];
+#pragma unroll
+            for (int z = 0; z < SW * CW; ++z) wp[z] = 0.0;
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int i = tid + PQ_THREADS * q;
+                if (i < m) {
+                    double x[CW];
+#pragma unroll
+                    for (int cc = 0; cc < CW; ++cc) x[cc] = P[i + (size_t)(cs + cc) * ld];
+#pragma unroll
+                    for (int c = 0; c < SW; ++c) {
+                        const double vv = (i > js + c) ? a[q][c] : ((i == js + c) ? 1.0 : 0.0);
+#pragma unroll
+                        for (int cc = 0; cc < CW; ++cc) wp[c * CW + cc] += vv * x[cc];
+                    }
+                }
+            }
+            block_allreduce<SW * CW>(wp, red, lane, wave);
+            double w2[SW * CW];
+#pragma unroll
+            for (int c = 0; c < SW; ++c)
+#pragma unroll
+                for (int cc = 0; cc < CW; ++cc) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int z = 0; z <= c; ++z) s += Ts[z][c] * wp[z * CW + cc];   // (T_s^T wp)
+                    w2[c * CW + cc] = s;
+                }
+            // pass 2: X -= V_s w2 (X re-read from L2; each thread touches only its own rows)
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int i = tid + PQ_THREADS * q;
+                if (i < m) {
+                    double x[CW];
+#pragma unroll
+                    for (int cc = 0; cc < CW; ++cc) x[cc] = P[i + (size_t)(cs + cc) * ld];
+#pragma unroll
+                    for (int c = 0; c < SW; ++c) {
+                        const double vv = (i > js + c) ? a[q][c] : ((i == js + c) ? 1.0 : 0.0);
+#pragma unroll
+                        for (int cc = 0; cc < CW; ++cc) x[cc] -= vv * w2[c * CW + cc];
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < CW; ++cc) P[i + (size_t)(cs + cc) * ld] = x[cc];
+                }
+            }
+        }
+        __syncthreads();   // panel columns written by this sub-panel are read by the next one
+    }
+}
+
+// T (NB x NB, upper triangular, column-major) from G = V^T V and tau: T(j,j) = tau_j,
+// T(0:j, j) = -tau_j T(0:j,0:j) G(0:j, j)   (LAPACK dlarft, forward / columnwise).
+__global__ __launch_bounds__(64) void form_T_kernel(const double *__restrict__ Gall,
+                                                   const double *__restrict__ tauall, double *Tall)
+{
+    __shared__ double T[NB][NB + 1];
+    __shared__ double G[NB][NB + 1];
+    const int i = threadIdx.x;
+    const size_t ch = blockIdx.x;
+    const double *Gg = Gall + ch * NB * NB;
+    const double *tau = tauall + ch * NB;
+    double *Tg = Tall + ch * NB * NB;
+    for (int j = 0; j < NB; ++j) { G[i][j] = Gg[i * NB + j]; T[i][j] = 0.0; }
+    __syncthreads();
+    for (int j = 0; j < NB; ++j) {
+        double s = 0.0;
+        if (i < j)
+            for (int p = i; p < j; ++p) s += T[i][p] * G[p][j];
+        __syncthreads();
+        const double tj = tau[j];
+        if (i < j) T[i][j] = -tj * s;
+        if (i == j) T[i][j] = tj;
+        __syncthreads();
+    }
+    for (int j = 0; j < NB; ++j) Tg[i + j * NB] = T[i][j];
+}
+
+__global__ void extract_band_kernel(int npad, const double *__restrict__ Aall, double *__restrict__ ABall)
+{
+    // AB[d + j*2NB] = A(j+d, j), d = 0..NB ; zero for d > NB or j+d >= npad
+    const size_t ch = blockIdx.y;
+    const double *A = Aall + ch * (size_t)npad * npad;
+    double *AB = ABall + ch * (size_t)npad * 2 * NB;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npad * 2 * NB) return;
+    const int d = idx % (2 * NB), j = idx / (2 * NB);
+    double v = 0.0;
+    if (d <= NB && j + d < npad) v = A[(size_t)j * npad + j + d];
+    AB[idx] = v;
+}
+
+size_t sy2sb_work_bytes(int npad, int nb, int batch)
+{
+    (void)nb;
+    size_t per = (size_t)npad * 3 * NB + (size_t)npad * NB + 3 * NB * NB + NB;
+    return per * batch * sizeof(double);
+}
+
+void sy2sb_carve(void *base, int npad, int nb, int batch, Sy2sbWork *w)
+{
+    (void)nb;
+    double *p = static_cast<double *>(base);
+    w->buf = p; p += (size_t)batch * npad * 3 * NB;
+    w->W = p; p += (size_t)batch * npad * NB;
+    w->G = p; p += (size_t)batch * NB * NB;
+    w->T = p; p += (size_t)batch * NB * NB;
+    w->Kmat = p; p += (size_t)batch * NB * NB;
+    w->tau = p;
+}
+
+template <int RPT>
+static void launch_pq(int npad, int r0, int c0, int batch, double *A, double *buf, double *tau, hipStream_t st)
+{
+    hipLaunchKernelGGL((panel_qr_kernel<RPT>), dim3(batch), dim3(PQ_THREADS), 0, st, npad, r0, c0, A, buf, tau);
+}
+
+int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipStream_t st)
+{
+    if (nb != NB || npad % NB != 0) return BSP_ERR_ARG;
+    if (npad - NB > PQ_THREADS * 16) return BSP_ERR_UNSUPPORTED;   // n <= 8256
+    const long ld = npad;
+    const long bsA = (long)npad * npad, bsBuf = (long)npad * 3 * NB, bsW = (long)npad * NB, bsS = NB * NB;
+    for (int c0 = 0; c0 + NB < npad; c0 += NB) {
+        const int r0 = c0 + NB, m = npad - r0;
+        const int rpt = (m + PQ_THREADS - 1) / PQ_THREADS;
+        if (rpt <= 1) launch_pq<1>(npad, r0, c0, batch, d_A, w.buf, w.tau, st);
+        else if (rpt <= 2) launch_pq<2>(npad, r0, c0, batch, d_A, w.buf, w.tau, st);
+        else if (rpt <= 4) launch_pq<4>(npad, r0, c0, batch, d_A, w.buf, w.tau, st);
+        else if (rpt <= 8) launch_pq<8>(npad, r0, c0, batch, d_A, w.buf, w.tau, st);
+        else launch_pq<16>(npad, r0, c0, batch, d_A, w.buf, w.tau, st);
+        BSP_HIP(hipGetLastError());
+        int rc;
+        GemmDesc g{};
+        g.batch = batch; g.lower_only = 0;
+        // G = V^T V
+        g.M = NB; g.N = NB; g.K = m;
+        g.A = w.buf; g.sAm = npad; g.sAk = 1; g.bA = bsBuf;
+        g.B = w.buf; g.sBk = 1; g.sBn = npad; g.bB = bsBuf;
+        g.C = w.G; g.sCm = NB; g.sCn = 1; g.bC = bsS; g.alpha = 1.0; g.beta = 0.0;
+        if ((rc = gemm_f64(g, st))) return rc;
+        hipLaunchKernelGGL(form_T_kernel, dim3(batch), dim3(64), 0, st, w.G, w.tau, w.T);
+        BSP_HIP(hipGetLastError());
+        // W = V T
+        g.M = m; g.N = NB; g.K = NB;
+        g.A = w.buf; g.sAm = 1; g.sAk = npad; g.bA = bsBuf;
+        g.B = w.T; g.sBk = 1; g.sBn = NB; g.bB = bsS;
+        g.C = w.W; g.sCm = 1; g.sCn = npad; g.bC = bsW; g.alpha = 1.0; g.beta = 0.0;
+        if ((rc = gemm_f64(g, st))) return rc;
+        // Y = A22 W  -> buf[:, NB:2NB]
+        double *A22 = d_A + (size_t)r0 * ld + r0;
+        g.M = m; g.N = NB; g.K = m;
+        g.A = A22; g.sAm = 1; g.sAk = ld; g.bA = bsA;
+        g.B = w.W; g.sBk = 1; g.sBn = npad; g.bB = bsW;
+        g.C = w.buf + (size_t)NB * npad; g.sCm = 1; g.sCn = npad; g.bC = bsBuf; g.alpha = 1.0; g.beta = 0.0;
+        if ((rc = gemm_f64(g, st))) return rc;
+        // K = W^T Y
+        g.M = NB; g.N = NB; g.K = m;
+        g.A = w.W; g.sAm = npad; g.sAk = 1; g.bA = bsW;
+        g.B = w.buf + (size_t)NB * npad; g.sBk = 1; g.sBn = npad; g.bB = bsBuf;
+        g.C = w.Kmat; g.sCm = 1; g.sCn = NB; g.bC = bsS; g.alpha = 1.0; g.beta = 0.0;
+        if ((rc = gemm_f64(g, st))) return rc;
+        // Z = Y - 1/2 V K  (in place)
+        g.M = m; g.N = NB; g.K = NB;
+        g.A = w.buf; g.sAm = 1; g.sAk = npad; g.bA = bsBuf;
+        g.B = w.Kmat; g.sBk = 1; g.sBn = NB; g.bB = bsS;
+        g.C = w.buf + (size_t)NB * npad; g.sCm = 1; g.sCn = npad; g.bC = bsBuf; g.alpha = -0.5; g.beta = 1.0;
+        if ((rc = gemm_f64(g, st))) return rc;
+        // A22 -= [V Z] [Z V]^T
+        g.M = m; g.N = m; g.K = 2 * NB;
+        g.A = w.buf; g.sAm = 1; g.sAk = npad; g.bA = bsBuf;
+        g.B = w.buf + (size_t)NB * npad; g.sBk = npad; g.sBn = 1; g.bB = bsBuf;
+        g.C = A22; g.sCm = 1; g.sCn = ld; g.bC = bsA; g.alpha = -1.0; g.beta = 1.0;
+        if ((rc = gemm_f64(g, st))) return rc;
+    }
+    return BSP_OK;
+}
+
+int launch_extract_band(int npad, int nb, int batch, const double *d_A, double *d_AB, hipStream_t st)
+{
+    if (nb != NB) return BSP_ERR_ARG;
+    const int total = npad * 2 * NB;
+    hipLaunchKernelGGL(extract_band_kernel, dim3((total + 255) / 256, batch), dim3(256), 0, st, npad, d_A, d_AB);
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
+
+}  // namespace bsp

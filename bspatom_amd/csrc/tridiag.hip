@@ -1,0 +1,103 @@
+// tridiag.hip -- all eigenvalues of the symmetric tridiagonal matrices by Sturm-sequence bisection.
+// Replaces DSTEQR/DSTERF inside DSYEV/DSYGV (reference call matrices.f90:248).  Batched over the
+// l-channels: grid = (ceil(n/256), batch); thread m of a channel brackets eigenvalue m (0-based,
+// ascending, like LAPACK's w) and bisects until the bracket cannot shrink.  d and e^2 of the
+// channel are staged in LDS (2 x 8 B x n; n <= 8192 -> 128 KiB) and every thread of the
+// workgroup walks them in lock-step, so each LDS read is a broadcast.
+//
+// count(x) = #{eigenvalues < x} from the LDL^T pivots q_i = (d_i - x) - e_{i-1}^2 / q_{i-1}
+// (LAPACK dstebz/dlaebz recurrence with the pivmin safeguard).
+#include "common.h"
+
+namespace bsp {
+
+__device__ __forceinline__ int sturm_count(const double *__restrict__ d, const double *__restrict__ e2,
+                                           int n, double x, double pivmin)
+{
+    double q = d[0] - x;
+    if (fabs(q) < pivmin) q = -pivmin;
+    int cnt = (q < 0.0) ? 1 : 0;
+    for (int i = 1; i < n; ++i) {
+        q = (d[i] - x) - e2[i - 1] / q;
+        if (fabs(q) < pivmin) q = -pivmin;
+        cnt += (q < 0.0) ? 1 : 0;
+    }
+    return cnt;
+}
+
+__global__ __launch_bounds__(256) void bisect_kernel(int n, int ldn, const double *__restrict__ dall,
+                                                    const double *__restrict__ eall, double *wall, long ldw)
+{
+    extern __shared__ double sm[];
+    double *d = sm, *e2 = sm + n;
+    __shared__ double red[8];
+    const int tid = threadIdx.x;
+    const size_t ch = blockIdx.y;
+    const double *dg = dall + ch * (size_t)ldn, *eg = eall + ch * (size_t)ldn;
+    double gl = 1e300, gu = -1e300, emax = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        const double di = dg[i];
+        const double el = (i > 0) ? fabs(eg[i - 1]) : 0.0;
+        const double er = (i < n - 1) ? fabs(eg[i]) : 0.0;
+        d[i] = di;
+        e2[i] = (i < n - 1) ? eg[i] * eg[i] : 0.0;
+        gl = fmin(gl, di - el - er);
+        gu = fmax(gu, di + el + er);
+        emax = fmax(emax, er * er);
+    }
+    // workgroup min/max
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        gl = fmin(gl, __shfl_xor(gl, off));
+        gu = fmax(gu, __shfl_xor(gu, off));
+        emax = fmax(emax, __shfl_xor(emax, off));
+    }
+    if ((tid & 63) == 0) { red[tid >> 6] = gl; red[4 + (tid >> 6)] = gu; }
+    __syncthreads();
+    gl = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+    gu = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = emax;
+    __syncthreads();
+    emax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    const double safmin = 2.2250738585072014e-308;
+    const double pivmin = safmin * fmax(1.0, emax);
+    const double tnorm = fmax(fabs(gl), fabs(gu));
+    const double eps = 2.220446049250313e-16;
+    gl = gl - 2.1 * tnorm * eps * n - 2.1 * pivmin;
+    gu = gu + 2.1 * tnorm * eps * n + 2.1 * pivmin;
+
+    const int m = blockIdx.x * 256 + tid;      // eigenvalue index
+    const bool act = m < n;
+    double lo = gl, hi = gu;
+    // every thread runs the same number of steps (LDS broadcast reads stay uniform); a thread
+    // whose bracket has converged keeps evaluating its midpoint harmlessly.
+    for (int it = 0; it < 128; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        const bool done = (mid <= lo) || (mid >= hi) || (hi - lo <= 2.0 * eps * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin);
+        if (__syncthreads_and(done)) break;
+        const int c = sturm_count(d, e2, n, mid, pivmin);
+        if (!done) {
+            if (c > m) hi = mid; else lo = mid;
+        }
+    }
+    if (act) wall[ch * (size_t)ldw + m] = 0.5 * (lo + hi);
+}
+
+int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_e, double *d_w, long ldw,
+                  hipStream_t st)
+{
+    const size_t lds = (size_t)2 * n * sizeof(double);
+    if (lds > 150 * 1024) return BSP_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(bisect_kernel, dim3((n + 255) / 256, batch), dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
+
+}  // namespace bsp

@@ -1,0 +1,113 @@
+/*
+ * bspatom.h -- C ABI of libbspatom: MI355X (gfx950) drop-in for the hot path of
+ * carlosmwh1985/BspAtom: MATRIX_SVT + SOLVE_SYSTEM (reference src/matrices.f90:1-394), i.e. the
+ * Gauss-Legendre assembly of the banded S, H(l) and the LAPACK DSYGV generalized eigen-solve.
+ *
+ * The reference has no plugin API: MATRIX_SVT / SOLVE_SYSTEM take no arguments and talk through
+ * Fortran module globals (src/Modules.f90:21-203).  This header is therefore the explicit form
+ * of that implicit interface; each entry point names the reference code it replaces.
+ * All pointers are plain host pointers unless the name says `_dev`; the caller owns every
+ * buffer it passes; the library owns the device memory of a problem between create/destroy.
+ * All calls are blocking and must come from one host thread per problem.
+ * Return value: 0 = ok, < 0 = BSPATOM_ERR_*, per-channel LAPACK-style codes go to `info[]`.
+ */
+#ifndef BSPATOM_H
+#define BSPATOM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSPATOM_OK 0
+#define BSPATOM_ERR_HIP (-1)         /* HIP runtime error (text on stderr) */
+#define BSPATOM_ERR_ARG (-2)         /* invalid argument */
+#define BSPATOM_ERR_BSPLVB (-3)      /* 'FATAL ERROR - BSPLVB' STOP of bsplvb.f90:30-34 */
+#define BSPATOM_ERR_NOGPU (-4)       /* no gfx950 device: there is no CPU fallback */
+#define BSPATOM_ERR_UNSUPPORTED (-5)
+
+/* Namelist values of VARS_BSP / VARS_TISE (src/ReadInputs.f90:15-17) with the reference's
+ * defaults (:27-36, :75-84) as the zero-initialised-then-`bspatom_input_defaults` state. */
+typedef struct bspatom_input {
+    int32_t kind_grid, k, ka, nfun, kind_bc1, kind_bc2;
+    double ra, rb, rmax;
+    int32_t n0_ini, l_ini, m_ini, l_fin, lmax, kind_pot;
+    double emax_fin, zatom;
+} bspatom_input;
+
+/* Sizes derived exactly as READ_INPUTS does (src/ReadInputs.f90:39-69, :87). */
+typedef struct bspatom_sizes {
+    int32_t nfun, k, ka, nkp, nointv, nbc1, nbc2, lmax, nintv_exp, nintv_lin, npad;
+} bspatom_sizes;
+
+typedef struct bspatom_problem bspatom_problem;   /* opaque */
+
+/* ---- set-up: READ_INPUTS sizes + GRID + gauleg + SELPOT tables (host), upload ------------- */
+void bspatom_input_defaults(bspatom_input *in);                       /* ReadInputs.f90:27-36,75-84 */
+int bspatom_device_count(void);
+/* Creates the problem on HIP device `device`: derives sizes (ReadInputs.f90:39-141), builds the knot
+ * sequence and Aind (grid.f90:14-91), the Gauss-Legendre rule (Modules.f90:112-153) and the
+ * potential table (Modules.f90:263-295) on the host, uploads them. */
+int bspatom_problem_create(const bspatom_input *in, int device, bspatom_problem **out);
+void bspatom_problem_destroy(bspatom_problem *p);
+int bspatom_problem_sizes(const bspatom_problem *p, bspatom_sizes *s);
+/* Host copies of rt[nkp], aind[2*nfun] (column-major Aind(nfun,2)), xg[ka], wg[ka]; any may be NULL. */
+int bspatom_problem_grid(const bspatom_problem *p, double *rt, double *aind, double *xg, double *wg);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+/* MATRIX_SVT (matrices.f90:68-186) + `Hij = Tij + Uij(:,:,l) + Vij` (:244) for channels
+ * l0 .. l0+nl-1, upper bands: SB[d*nfun + i] = S(i,i+d); HB[(l*k + d)*nfun + i] = H_l(i,i+d),
+ * 0-based, d < k.  Bit-identical to the reference's dense matrices on the band.  SB/HB may be NULL
+ * (results stay on the device for bspatom_solve). */
+int bspatom_assemble(bspatom_problem *p, int l0, int nl, double *SB, double *HB);
+
+/* SOLVE_SYSTEM's l-loop (matrices.f90:242-265): assembly + DSYGV eigenvalues for channels
+ * l0 .. l0+nl-1.  E[l*nfun + i] ascending per channel (column-major Enl(nfun,0:lmax), :230).
+ * info[l]: 0 ok; nfun+i: leading minor i of S not positive definite (DSYGV convention, :250-254). */
+int bspatom_solve(bspatom_problem *p, int l0, int nl, double *E, int32_t *info);
+/* Same, spectra left in device memory (E_dev: nl*nfun doubles on the problem's device, e.g. a
+ * torch tensor's data_ptr) so that ranks can exchange them with RCCL without a host round trip. */
+int bspatom_solve_dev(bspatom_problem *p, int l0, int nl, double *E_dev, int32_t *info);
+
+/* Eigenvector column `n0` (1-based, as n0_ini) of channel l -- the only column of DSYGV's 'V'
+ * output that KIND_PI=0 consumes (matrices.f90:267): inverse iteration on the banded pencil
+ * (H_l - E S), normalised c^T S c = 1; sign arbitrary (CHKPHS is commented out, :382).
+ * Requires a previous bspatom_solve covering channel l.  c[nfun]. */
+int bspatom_eigvec(bspatom_problem *p, int l, int n0, double *c);
+
+/* WRITE_WF (Bsp_Atom.f90:118-146): u(r_i) = sum_j c_j B_j(r_i), r_i = ra + i*(rb-ra)/npts,
+ * i = 0..npts.  Returns BSPATOM_ERR_BSPLVB where the reference STOPs. r[npts+1], u[npts+1]. */
+int bspatom_write_wf(bspatom_problem *p, const double *c, int npts, double *r, double *u);
+
+/* Per-stage device time of the last bspatom_solve* call, HIP events on the library's stream
+ * (milliseconds): [0] point table + bands, [1] Cholesky + standard form, [2] sy2sb,
+ * [3] sb2st, [4] bisection, [5] total.  Also the number of launches of the sy2sb GEMM. */
+int bspatom_last_timing(const bspatom_problem *p, double ms[6]);
+
+/* ---- LAPACK symbol boundary ---------------------------------------------------- */
+/* Fortran-77 ABI of DSYGV as called at matrices.f90:248.  ITYPE=1, UPLO='U' or 'L'; A and B must
+ * be banded with half-width <= 15 (they are, at the reference's call site); JOBZ='N' returns the
+ * eigenvalues, JOBZ='V' additionally returns S-orthonormal eigenvectors by inverse iteration.
+ * info = -k for a bad k-th argument, n+i if B is not positive definite. */
+void bsp_dsygv_(const int *itype, const char *jobz, const char *uplo, const int *n, double *a,
+                const int *lda, double *b, const int *ldb, double *w, double *work, const int *lwork,
+                int *info, int jobz_len, int uplo_len);
+
+/* ---- stage-level entry points (parity tests, profiling; host buffers, column-major) ---------- */
+/* C[b] = alpha * op(A[b]) op(B[b]) + beta * C[b], element strides as in csrc/common.h GemmDesc. */
+int bspatom_stage_gemm(int M, int N, int K, int batch, const double *A, long sAm, long sAk, long bA,
+                       long lenA, const double *B, long sBk, long sBn, long bB, long lenB, double *C,
+                       long sCm, long sCn, long bC, long lenC, double alpha, double beta);
+/* S = U^T U and C_l = U^-T H_l U^-1 from upper bands (n, k as above); C: nl x npad x npad. */
+int bspatom_stage_standard_form(int n, int k, int nl, const double *SB, const double *HB, double *UB,
+                                double *C, int32_t *info);
+/* dense symmetric (npad multiple of 64, full storage) -> lower band AB[d + j*128], d <= 64 */
+int bspatom_stage_sy2sb(int npad, int batch, const double *A, double *AB);
+/* band (AB as above, leading n x n) -> tridiagonal d[n], e[n-1] (ld npad) */
+int bspatom_stage_sb2st(int n, int npad, int batch, const double *AB, double *d, double *e);
+/* eigenvalues of tridiagonal matrices, ascending */
+int bspatom_stage_bisect(int n, int batch, const double *d, const double *e, double *w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
