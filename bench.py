@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- l-channel eigensolves/sec at N_bsp = 4096 (BASELINE.json metric) on N MI355X.
+
+One "step" = one pass of the hot path over one batch of l-channels per GPU, inputs resident in HBM:
+  assembly of S and H(l) bands -> banded Cholesky -> standard form -> sy2sb -> sb2st -> bisection
+  (all nfun eigenvalues of every channel) + the (l_ini, n0_ini) eigenvector and its WRITE_WF table
+  on the rank that owns l_ini + the RCCL all-gather of the spectra.
+Workload (BASELINE configs[3], "Hydrogen l=0..127, N_bsp=4096"): KIND_GRID=0 ra=0 rb=800 k=9
+nfun=4096 Zatom=1; every GPU solves `--channels` (default 128) consecutive l-channels: rank r takes
+l = r*channels .. (r+1)*channels-1 (cost per channel does not depend on l) -> weak scaling, no
+data-path collective except the final gather.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant stage,
+HIP-event time measured live on the library's stream) and `cpu_baseline` (the compiled reference
+oracle/_ref/ref_dump.x when present, else the CPU oracle port) objects.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6     # MI355X fp64 vector = matrix peak (datasheet)
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(sample_nfun, k):
+    """Time the reference path (MATRIX_SVT + SOLVE_SYSTEM, one l-channel) on the host cores."""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(avail, 16)            # one GPU's CPU share on the bench box; pins the BLAS thread count
+    env = dict(os.environ, OPENBLAS_NUM_THREADS=str(cores), OMP_NUM_THREADS=str(cores))
+    refx = os.path.join(ROOT, "oracle", "_ref", "ref_dump.x")
+    rb = 800.0 * sample_nfun / 4096.0
+    nml = ("&VARS_BSP KIND_GRID=0 ra=0.0D0 rb=%.1fD0 k=%d nfun=%d &end\n"
+           "&VARS_TISE n0_ini=1 l_ini=0 l_fin=0 Zatom=1.0D0 &end\n&VARS_FIELD KIND_PI=0 &end\n" % (rb, k, sample_nfun))
+    if os.path.exists(refx):
+        try:
+            with tempfile.TemporaryDirectory(prefix="bspbench.") as tmp:
+                t0 = time.time()
+                p = subprocess.run([refx], input=nml, cwd=tmp, capture_output=True, text=True, timeout=600, env=env)
+                wall = time.time() - t0
+            tim = {l.split()[0]: float(l.split()[1]) for l in p.stdout.split("\n") if l.startswith("REF_TIME_")}
+            if p.returncode == 0 and "REF_TIME_SOLVE_SYSTEM_S" in tim:
+                t = tim["REF_TIME_MATRIX_SVT_S"] + tim["REF_TIME_SOLVE_SYSTEM_S"]
+                return {"value": 1.0 / t, "unit": "eigensolves/s", "cores": cores, "kind": "reference",
+                        "sample": "1 l-channel at nfun=%d k=%d (compiled reference: MATRIX_SVT %.2fs + SOLVE_SYSTEM/DSYGV('V') "
+                                  "%.2fs, flang -O2, OpenBLAS LAPACK 3.12; wall %.1fs); nfun=4096 costs ~8x more per channel"
+                                  % (sample_nfun, k, tim["REF_TIME_MATRIX_SVT_S"], tim["REF_TIME_SOLVE_SYSTEM_S"], wall),
+                        "value_scaled_to_nfun4096": (1.0 / t) * (sample_nfun / 4096.0) ** 3}
+        except Exception as e:     # fall through to the port
+            sys.stderr.write("cpu_baseline: reference binary failed (%s), using the oracle port\n" % e)
+    os.environ["OPENBLAS_NUM_THREADS"] = str(cores)
+    import oracle as orc
+    c = orc.make_cfg(kind_grid=0, ra=0.0, rb=rb, k=k, nfun=sample_nfun, l_fin=0, zatom=1.0)
+    t0 = time.time()
+    orc.solve_all(c)
+    t = time.time() - t0
+    return {"value": 1.0 / t, "unit": "eigensolves/s", "cores": cores, "kind": "port",
+            "sample": "1 l-channel at nfun=%d k=%d (oracle: banded assembly + scipy LAPACK dsygv 'V'); nfun=4096 ~8x more"
+                      % (sample_nfun, k),
+            "value_scaled_to_nfun4096": (1.0 / t) * (sample_nfun / 4096.0) ** 3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nfun", type=int, default=4096)
+    ap.add_argument("--k", type=int, default=9)
+    ap.add_argument("--rb", type=float, default=800.0)
+    ap.add_argument("--channels", type=int, default=128, help="l-channels per GPU")
+    ap.add_argument("--cpu-sample-nfun", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch                      # first: its HIP runtime is the one the process uses
+    import torch.distributed as dist
+    import numpy as np
+    from bspatom_amd import capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write("bench: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE\n" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libbspatom has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+
+    nl = args.channels
+    l0 = rank * nl
+    inp = capi.make_input(kind_grid=0, ra=0.0, rb=args.rb, k=args.k, nfun=args.nfun, n0_ini=1, l_ini=0,
+                          l_fin=world * nl - 1, zatom=1.0)
+    prob = capi.Problem(inp, device=local)
+    n = prob.nfun
+    E_dev = torch.empty(nl * n, dtype=torch.float64, device="cuda")
+    E_all = torch.empty(world * nl * n, dtype=torch.float64, device="cuda") if world > 1 else E_dev
+
+    stage_ms = np.zeros(6)
+
+    def step(timed):
+        info = prob.solve_dev(l0, nl, E_dev.data_ptr())
+        assert (info == 0).all()
+        if timed:
+            t = prob.last_timing()
+            stage_ms[:] += [t["assemble"], t["chol_std"], t["sy2sb"], t["sb2st"], t["bisect"], t["total"]]
+        if rank == 0:                 # owner of l_ini = 0: the one eigenvector KIND_PI=0 consumes + WRITE_WF
+            c = prob.eigvec(0, 1)
+            prob.write_wf(c)
+        if world > 1:
+            dist.all_gather_into_tensor(E_all, E_dev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        Eh = E_all[: n].cpu().numpy()
+        ryd = max(abs(Eh[i] + 0.5 / (i + 1) ** 2) / (0.5 / (i + 1) ** 2) for i in range(8))
+        stage_ms /= max(args.steps, 1)
+        units = world * nl * args.steps
+        value = units / dt
+        b = 64
+        F = 4.0 / 3.0 * n ** 3 + 4.0 * n ** 2 * args.k            # SURVEY 8(d) flops per l-channel
+        names = ["assemble", "chol_std", "sy2sb", "sb2st", "bisect"]
+        dom = int(np.argmax(stage_ms[:5]))
+        if names[dom] == "sb2st":
+            # bulge chasing: every chase step reads and writes one b x b block and one b x b symmetric
+            # block (1.5 b^2 doubles each way): 24 b^2 B per step, n^2/(2b) steps -> 12 n^2 b bytes/channel
+            alg = 12.0 * n * n * b * nl
+            roof = {"kernel": "sb2st_kernel", "bound": "hbm", "achieved": alg / (stage_ms[dom] * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        elif names[dom] == "sy2sb":
+            alg = 4.0 / 3.0 * n ** 3 * nl
+            roof = {"kernel": "sy2sb (gemm_kernel + panel_qr_kernel)", "bound": "mfma",
+                    "achieved": alg / (stage_ms[dom] * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s"}
+        else:
+            alg = 16.0 * n * n * nl                                # write + read dense C_l once
+            roof = {"kernel": names[dom], "bound": "hbm", "achieved": alg / (stage_ms[dom] * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = None
+        roof["launch_ms"] = float(stage_ms[dom])
+        out = {
+            "metric": "l-channel eigensolves/sec at N_bsp=%d fp64" % n, "value": value, "unit": "eigensolves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Hydrogen Coulomb l=%d..%d, N_bsp=%d, k=%d, KIND_GRID=0 rb=%g (BASELINE configs[3]); "
+                                   "%d l-channels per GPU" % (0, world * nl - 1, n, args.k, args.rb, nl),
+                       "channels_per_gpu": nl, "parallelism": "l-sharded x%d, RCCL all-gather of spectra" % world},
+            "roofline": roof,
+            "tridiag_tflops_F(n)": F * value / 1e12, "tridiag_frac_of_fp64_peak": F * value / 1e12 / (FP64_PEAK_TFLOPS * world),
+            "stage_ms_per_step_rank0": dict(zip(names + ["total_device"], [float(x) for x in stage_ms])),
+            "rydberg_max_rel_err_n<=8": ryd,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_nfun, args.k)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    prob.close()
+
+
+if __name__ == "__main__":
+    main()
