@@ -31,7 +31,7 @@ class Sizes(C.Structure):
                                          "nintv_exp", "nintv_lin", "npad")]
 
 
-EXPORTS = ["bspatom_input_defaults", "bspatom_device_count", "bspatom_problem_create", "bspatom_problem_destroy",
+EXPORTS = ["bspatom_input_defaults", "bspatom_device_count", "bspatom_host_setup", "bspatom_problem_create", "bspatom_problem_destroy",
            "bspatom_problem_sizes", "bspatom_problem_grid", "bspatom_assemble", "bspatom_solve", "bspatom_solve_dev",
            "bspatom_eigvec", "bspatom_write_wf", "bspatom_last_timing", "bsp_dsygv_", "bspatom_stage_gemm",
            "bspatom_stage_standard_form", "bspatom_stage_sy2sb", "bspatom_stage_sb2st", "bspatom_stage_bisect"]
@@ -49,6 +49,7 @@ def lib():
         vp, i32, dbl, lng = C.c_void_p, C.c_int, C.c_double, C.c_long
         L.bspatom_input_defaults.argtypes = [C.POINTER(Input)]
         L.bspatom_input_defaults.restype = None
+        L.bspatom_host_setup.argtypes = [C.POINTER(Input), C.POINTER(Sizes), vp, vp, vp, vp]
         L.bspatom_problem_create.argtypes = [C.POINTER(Input), i32, C.POINTER(vp)]
         L.bspatom_problem_destroy.argtypes = [vp]
         L.bspatom_problem_destroy.restype = None
@@ -89,6 +90,17 @@ def make_input(**kw):
         if key in names:
             setattr(inp, key, v)
     return inp
+
+
+def host_setup(inp, arrays=True):
+    """READ_INPUTS sizes and GRID/gauleg arrays, computed on the host (works without a GPU)."""
+    s = Sizes()
+    _chk(lib().bspatom_host_setup(C.byref(inp), C.byref(s), None, None, None, None), "bspatom_host_setup")
+    if not arrays:
+        return s
+    rt = np.zeros(s.nkp); aind = np.zeros(2 * s.nfun); xg = np.zeros(s.ka); wg = np.zeros(s.ka)
+    _chk(lib().bspatom_host_setup(C.byref(inp), C.byref(s), _p(rt), _p(aind), _p(xg), _p(wg)), "bspatom_host_setup")
+    return s, rt, aind, xg, wg
 
 
 class Problem:

@@ -45,6 +45,25 @@ extern "C" int bspatom_device_count(void)
     return n;
 }
 
+extern "C" int bspatom_host_setup(const bspatom_input *in, bspatom_sizes *s, double *rt, double *aind, double *xg,
+                                  double *wg)
+{
+    if (!in || !s) return BSP_ERR_ARG;
+    HostSetup h;
+    if (derive(*in, &h) != 0) return BSP_ERR_ARG;
+    s->nfun = h.nfun; s->k = h.k; s->ka = h.ka; s->nkp = h.nkp; s->nointv = h.nointv;
+    s->nbc1 = h.nbc1; s->nbc2 = h.nbc2; s->lmax = h.lmax; s->nintv_exp = h.nintv_exp;
+    s->nintv_lin = h.nintv_lin; s->npad = round_up(h.nfun, 64);
+    if (rt || aind || xg || wg) {
+        build_grid(&h);
+        if (rt) memcpy(rt, h.rt.data(), h.rt.size() * sizeof(double));
+        if (aind) memcpy(aind, h.aind.data(), h.aind.size() * sizeof(double));
+        if (xg) memcpy(xg, h.xg.data(), h.xg.size() * sizeof(double));
+        if (wg) memcpy(wg, h.wg.data(), h.wg.size() * sizeof(double));
+    }
+    return BSP_OK;
+}
+
 static void free_solve_buffers(bspatom_problem *p)
 {
     hipFree(p->d_SB); hipFree(p->d_HB); hipFree(p->d_UB); hipFree(p->d_rdiag); hipFree(p->d_Y);

@@ -43,58 +43,53 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc g)
         for (int j = 0; j < TN; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
     for (int k0 = 0; k0 < g.K; k0 += BK) {
+        // Staging loads are UNCONDITIONAL from clamped addresses, the value is selected afterwards:
+        // a branch around a load makes hipcc wait vmcnt(0) per load (serialised round trips).
+        // M, N are even and K is a multiple of 2 for every caller (checked in gemm_f64).
         // ---- stage A tile (BM x BK) ----
         if (ALAY == 0) {   // contiguous along m: double2 along m
-            for (int idx = tid; idx < BK * BM / 2; idx += 256) {
-                int kk = idx / (BM / 2), mm = (idx % (BM / 2)) * 2;
-                int gm = m0 + mm, gk = k0 + kk;
-                double2 v = make_double2(0.0, 0.0);
-                if (gk < g.K) {
-                    const double *p = A + (long)gm + (long)gk * g.sAk;
-                    if (gm + 1 < g.M) v = *reinterpret_cast<const double2 *>(p);
-                    else if (gm < g.M) v.x = p[0];
-                }
-                *reinterpret_cast<double2 *>(&As[kk * LDA + mm]) = v;
+#pragma unroll
+            for (int it = 0; it < BK * BM / 2 / 256; ++it) {
+                const int idx = tid + it * 256;
+                const int kk = idx / (BM / 2), mm = (idx % (BM / 2)) * 2;
+                const int gm = m0 + mm, gk = k0 + kk;
+                const bool ok = (gk < g.K) && (gm + 1 < g.M);
+                const double2 v = *reinterpret_cast<const double2 *>(A + (ok ? ((long)gm + (long)gk * g.sAk) : 0));
+                *reinterpret_cast<double2 *>(&As[kk * LDA + mm]) = ok ? v : make_double2(0.0, 0.0);
             }
         } else {           // contiguous along k: double2 along k
-            for (int idx = tid; idx < BM * BK / 2; idx += 256) {
-                int mm = idx / (BK / 2), kk = (idx % (BK / 2)) * 2;
-                int gm = m0 + mm, gk = k0 + kk;
-                double2 v = make_double2(0.0, 0.0);
-                if (gm < g.M) {
-                    const double *p = A + (long)gm * g.sAm + (long)gk;
-                    if (gk + 1 < g.K) v = *reinterpret_cast<const double2 *>(p);
-                    else if (gk < g.K) v.x = p[0];
-                }
-                As[kk * LDA + mm] = v.x;
-                As[(kk + 1) * LDA + mm] = v.y;
+#pragma unroll
+            for (int it = 0; it < BM * BK / 2 / 256; ++it) {
+                const int idx = tid + it * 256;
+                const int mm = idx / (BK / 2), kk = (idx % (BK / 2)) * 2;
+                const int gm = m0 + mm, gk = k0 + kk;
+                const bool ok = (gm < g.M) && (gk + 1 < g.K);
+                const double2 v = *reinterpret_cast<const double2 *>(A + (ok ? ((long)gm * g.sAm + (long)gk) : 0));
+                As[kk * LDA + mm] = ok ? v.x : 0.0;
+                As[(kk + 1) * LDA + mm] = ok ? v.y : 0.0;
             }
         }
         // ---- stage B tile (BK x BN) ----
         if (BLAY == 0) {   // contiguous along n
-            for (int idx = tid; idx < BK * BN / 2; idx += 256) {
-                int kk = idx / (BN / 2), nn = (idx % (BN / 2)) * 2;
-                int gn = n0 + nn, gk = k0 + kk;
-                double2 v = make_double2(0.0, 0.0);
-                if (gk < g.K) {
-                    const double *p = B + (long)gn + (long)gk * g.sBk;
-                    if (gn + 1 < g.N) v = *reinterpret_cast<const double2 *>(p);
-                    else if (gn < g.N) v.x = p[0];
-                }
-                *reinterpret_cast<double2 *>(&Bs[kk * LDB + nn]) = v;
+#pragma unroll
+            for (int it = 0; it < BK * BN / 2 / 256; ++it) {
+                const int idx = tid + it * 256;
+                const int kk = idx / (BN / 2), nn = (idx % (BN / 2)) * 2;
+                const int gn = n0 + nn, gk = k0 + kk;
+                const bool ok = (gk < g.K) && (gn + 1 < g.N);
+                const double2 v = *reinterpret_cast<const double2 *>(B + (ok ? ((long)gn + (long)gk * g.sBk) : 0));
+                *reinterpret_cast<double2 *>(&Bs[kk * LDB + nn]) = ok ? v : make_double2(0.0, 0.0);
             }
         } else {           // contiguous along k
-            for (int idx = tid; idx < BN * BK / 2; idx += 256) {
-                int nn = idx / (BK / 2), kk = (idx % (BK / 2)) * 2;
-                int gn = n0 + nn, gk = k0 + kk;
-                double2 v = make_double2(0.0, 0.0);
-                if (gn < g.N) {
-                    const double *p = B + (long)gn * g.sBn + (long)gk;
-                    if (gk + 1 < g.K) v = *reinterpret_cast<const double2 *>(p);
-                    else if (gk < g.K) v.x = p[0];
-                }
-                Bs[kk * LDB + nn] = v.x;
-                Bs[(kk + 1) * LDB + nn] = v.y;
+#pragma unroll
+            for (int it = 0; it < BN * BK / 2 / 256; ++it) {
+                const int idx = tid + it * 256;
+                const int nn = idx / (BK / 2), kk = (idx % (BK / 2)) * 2;
+                const int gn = n0 + nn, gk = k0 + kk;
+                const bool ok = (gn < g.N) && (gk + 1 < g.K);
+                const double2 v = *reinterpret_cast<const double2 *>(B + (ok ? ((long)gn * g.sBn + (long)gk) : 0));
+                Bs[kk * LDB + nn] = ok ? v.x : 0.0;
+                Bs[(kk + 1) * LDB + nn] = ok ? v.y : 0.0;
             }
         }
         __syncthreads();
@@ -125,12 +120,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc g)
             for (int r = 0; r < 4; ++r) {
                 int gi = m0 + wm * (BM / WM) + i * 16 + (lane >> 4) + 4 * r;
                 int gj = n0 + wn * (BN / WN) + j * 16 + (lane & 15);
-                if (gi < g.M && gj < g.N) {
-                    double *p = C + (long)gi * g.sCm + (long)gj * g.sCn;
-                    double v = alpha * acc[i][j][r];
-                    if (beta != 0.0) v += beta * (*p);
-                    *p = v;
-                }
+                const bool ok = (gi < g.M && gj < g.N);
+                double *p = C + (ok ? ((long)gi * g.sCm + (long)gj * g.sCn) : 0);
+                double v = alpha * acc[i][j][r];
+                if (beta != 0.0) v += beta * (*p);       // wave-uniform condition, unconditional load
+                if (ok) *p = v;
             }
 }
 
@@ -168,6 +162,7 @@ int gemm_f64(const GemmDesc &gin, hipStream_t st)
     if (g.sAm == 1) alay = 0; else if (g.sAk == 1) alay = 1; else return BSP_ERR_ARG;
     if (g.sBn == 1) blay = 0; else if (g.sBk == 1) blay = 1; else return BSP_ERR_ARG;
     auto even = [](long v) { return (v & 1) == 0; };
+    if ((g.M & 1) || (g.N & 1) || (g.K & 1)) return BSP_ERR_ARG;
     if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || !even(g.bA) || !even(g.bB)) return BSP_ERR_ARG;
     if ((alay == 0 && !even(g.sAk)) || (alay == 1 && !even(g.sAm))) return BSP_ERR_ARG;
     if ((blay == 0 && !even(g.sBk)) || (blay == 1 && !even(g.sBn))) return BSP_ERR_ARG;

@@ -1,0 +1,187 @@
+!  bsp_atom_host.f90 -- Fortran host of libbspatom (ISO_C_BINDING over the C ABI in
+!  include/bspatom.h).  Drop-in for `Bsp_Atom_omp.x < bsp_0.inp` in KIND_PI = 0 mode:
+!  reads the three NAMELIST groups from stdin exactly as READ_INPUTS does (reference
+!  src/ReadInputs.f90:15-21,27-37,75-85,155-184), solves all l-channels on the MI355X, and
+!  writes stdout, Enl.dat and wf_n0.dat in the reference's formats
+!  (src/matrices.f90:239-240,256-265,388-391; src/Bsp_Atom.f90:118-146).
+      MODULE BSPATOM_C
+      USE ISO_C_BINDING
+      IMPLICIT NONE
+      TYPE, BIND(C) :: bspatom_input
+        INTEGER(C_INT32_T) :: kind_grid, k, ka, nfun, kind_bc1, kind_bc2
+        REAL(C_DOUBLE) :: ra, rb, rmax
+        INTEGER(C_INT32_T) :: n0_ini, l_ini, m_ini, l_fin, lmax, kind_pot
+        REAL(C_DOUBLE) :: emax_fin, zatom
+      END TYPE
+      TYPE, BIND(C) :: bspatom_sizes
+        INTEGER(C_INT32_T) :: nfun, k, ka, nkp, nointv, nbc1, nbc2, lmax, nintv_exp, nintv_lin, npad
+      END TYPE
+      INTERFACE
+        SUBROUTINE bspatom_input_defaults(inp) BIND(C, NAME='bspatom_input_defaults')
+          IMPORT :: bspatom_input
+          TYPE(bspatom_input), INTENT(OUT) :: inp
+        END SUBROUTINE
+        INTEGER(C_INT) FUNCTION bspatom_problem_create(inp, device, prob) BIND(C, NAME='bspatom_problem_create')
+          IMPORT :: bspatom_input, C_INT, C_PTR
+          TYPE(bspatom_input), INTENT(IN) :: inp
+          INTEGER(C_INT), VALUE :: device
+          TYPE(C_PTR), INTENT(OUT) :: prob
+        END FUNCTION
+        SUBROUTINE bspatom_problem_destroy(prob) BIND(C, NAME='bspatom_problem_destroy')
+          IMPORT :: C_PTR
+          TYPE(C_PTR), VALUE :: prob
+        END SUBROUTINE
+        INTEGER(C_INT) FUNCTION bspatom_problem_sizes(prob, s) BIND(C, NAME='bspatom_problem_sizes')
+          IMPORT :: bspatom_sizes, C_INT, C_PTR
+          TYPE(C_PTR), VALUE :: prob
+          TYPE(bspatom_sizes), INTENT(OUT) :: s
+        END FUNCTION
+        INTEGER(C_INT) FUNCTION bspatom_solve(prob, l0, nl, E, info) BIND(C, NAME='bspatom_solve')
+          IMPORT :: C_INT, C_PTR, C_DOUBLE, C_INT32_T
+          TYPE(C_PTR), VALUE :: prob
+          INTEGER(C_INT), VALUE :: l0, nl
+          REAL(C_DOUBLE), INTENT(OUT) :: E(*)
+          INTEGER(C_INT32_T), INTENT(OUT) :: info(*)
+        END FUNCTION
+        INTEGER(C_INT) FUNCTION bspatom_eigvec(prob, l, n0, c) BIND(C, NAME='bspatom_eigvec')
+          IMPORT :: C_INT, C_PTR, C_DOUBLE
+          TYPE(C_PTR), VALUE :: prob
+          INTEGER(C_INT), VALUE :: l, n0
+          REAL(C_DOUBLE), INTENT(OUT) :: c(*)
+        END FUNCTION
+        INTEGER(C_INT) FUNCTION bspatom_write_wf(prob, c, npts, r, u) BIND(C, NAME='bspatom_write_wf')
+          IMPORT :: C_INT, C_PTR, C_DOUBLE
+          TYPE(C_PTR), VALUE :: prob
+          REAL(C_DOUBLE), INTENT(IN) :: c(*)
+          INTEGER(C_INT), VALUE :: npts
+          REAL(C_DOUBLE), INTENT(OUT) :: r(*), u(*)
+        END FUNCTION
+      END INTERFACE
+      END MODULE BSPATOM_C
+
+      PROGRAM BSP_ATOM_MI355X
+      USE ISO_C_BINDING
+      USE BSPATOM_C
+      IMPLICIT NONE
+      INTEGER, PARAMETER :: DP = KIND(1.0D0)
+!     VARS_BSP / VARS_TISE / VARS_FIELD, same names and defaults as the reference
+      INTEGER :: KIND_GRID, k, ka, nfun, KIND_BC1, KIND_BC2, nfib
+      REAL(DP) :: ra, rb, rmax
+      INTEGER :: n0_ini, l_ini, m_ini, l_fin, lmax, KIND_POT, KIND_EGR, KIND_NLM
+      REAL(DP) :: Emax_fin, Zatom
+      INTEGER :: KIND_PI, KIND_SCP, KIND_TD, KIND_ENV, KIND_RK, KIND_VEC, ncyc, ncyc2, moam, mph
+      INTEGER :: nEpts, nthpts, nphpts
+      REAL(DP) :: A0, w0, Eph, Eph2, I0, I01, b0, afocus, Eref, bx, B0z, A01, t_delay, A0x, A0y, A0z
+      NAMELIST / VARS_BSP / KIND_GRID, ra, rb, rmax, k, ka, nfun, KIND_BC1, KIND_BC2, nfib
+      NAMELIST / VARS_TISE / n0_ini, l_ini, m_ini, l_fin, lmax, Emax_fin, Zatom, &
+     &                        KIND_POT, KIND_EGR, KIND_NLM
+      NAMELIST / VARS_FIELD / KIND_PI, KIND_SCP, KIND_TD, KIND_ENV, KIND_RK,  &
+     &                         KIND_VEC, A0, w0, Eph, ncyc, Eph2, ncyc2, moam, &
+     &                         mph, I0, I01, b0, afocus, nEpts, nthpts, nphpts,&
+     &                         Eref, bx, B0z, A01, t_delay, A0x, A0y, A0z
+      TYPE(bspatom_input) :: inp
+      TYPE(bspatom_sizes) :: sz
+      TYPE(C_PTR) :: prob
+      INTEGER(C_INT) :: rc
+      INTEGER :: l, i, npts
+      REAL(DP), ALLOCATABLE :: En(:), ci(:), r(:), u(:)
+      INTEGER(C_INT32_T), ALLOCATABLE :: info(:)
+
+      WRITE(6,'(A64)') 'PROGRAM TO CALCULATE ELECTRONIC STRUCTURE AND PI CROSS SECTIONS,'
+      WRITE(6,'(A17,/)') '  USING B-SPLINES'
+
+      KIND_GRID = 0; ra = 0.D0; rb = 0.D0; rmax = 0.D0; k = 0; ka = 0; nfun = 0
+      KIND_BC1 = 0; KIND_BC2 = 0; nfib = 1
+      READ(5,VARS_BSP)
+      KIND_POT = 0; n0_ini = 1; l_ini = 0; m_ini = 0; l_fin = 0; lmax = 0
+      Emax_fin = -1.D0; Zatom = 1.D0; KIND_EGR = 0; KIND_NLM = 0
+      READ(5,VARS_TISE)
+      KIND_PI = 0; KIND_SCP = 0; KIND_TD = 0; KIND_ENV = 0; KIND_RK = 6; KIND_VEC = 0
+      A0 = 0.D0; I0 = 0.D0; A01 = 0.D0; I01 = 0.D0; w0 = 0.D0; Eph = 0.D0; mph = 0; moam = 0
+      b0 = 0.D0; afocus = 0.D0; nEpts = 10; Eref = 0.D0; nthpts = 1; nphpts = 1; ncyc = 0
+      bx = 0.D0; B0z = 0.D0; t_delay = 0.D0; ncyc2 = 0; Eph2 = 0.D0; A0x = 0.D0; A0y = 0.D0; A0z = 1.D0
+      READ(5,VARS_FIELD)
+      IF( KIND_PI /= 0 ) THEN
+        WRITE(6,*) 'bsp_atom_host: only KIND_PI = 0 (electronic structure) is on the MI355X hot path'
+        STOP 2
+      END IF
+
+      CALL bspatom_input_defaults(inp)
+      inp%kind_grid = KIND_GRID; inp%k = k; inp%ka = ka; inp%nfun = nfun
+      inp%kind_bc1 = KIND_BC1; inp%kind_bc2 = KIND_BC2
+      inp%ra = ra; inp%rb = rb; inp%rmax = rmax
+      inp%n0_ini = n0_ini; inp%l_ini = l_ini; inp%m_ini = m_ini; inp%l_fin = l_fin; inp%lmax = lmax
+      inp%kind_pot = KIND_POT; inp%emax_fin = Emax_fin; inp%zatom = Zatom
+      rc = bspatom_problem_create(inp, 0_C_INT, prob)
+      IF( rc /= 0 ) THEN
+        WRITE(6,*) 'bsp_atom_host: bspatom_problem_create failed, code ', rc
+        STOP 1
+      END IF
+      rc = bspatom_problem_sizes(prob, sz)
+      IF( KIND_GRID == 2 ) THEN
+        WRITE(6,'(/,A29,I5)') 'Initial Number of Functions: ', nfun
+        WRITE(6,'(A29,I5)') 'Number of functions changed: ', sz%nfun
+      END IF
+      nfun = sz%nfun
+      lmax = sz%lmax
+      WRITE(6,'(A40,I5)') 'Number of B-spline Functions / l: nfun =', nfun
+      WRITE(6,'(/,A38,I3)') 'Max. Angular Momenta Included: l_max =', lmax
+      WRITE(6,'(/,A22,I6)') 'Number of Knot Points:' , sz%nkp
+      WRITE(6,'(A27,2I3)') 'Multiplicity of END points:', sz%nbc1, sz%nbc2
+      WRITE(6,'(/,A34)') 'Calculating S, V, U and T Matrices'
+
+      ALLOCATE( En(nfun*(lmax+1)), info(lmax+1), ci(nfun) )
+      rc = bspatom_solve(prob, 0_C_INT, INT(lmax+1,C_INT), En, info)
+      IF( rc /= 0 ) THEN
+        IF( rc == -3 ) WRITE(6,*) 'FATAL ERROR - BSPLVB'
+        WRITE(6,*) 'bsp_atom_host: bspatom_solve failed, code ', rc
+        STOP 1
+      END IF
+      WRITE(6,'(A19,/)') 'Matrices Calculated'
+
+      OPEN( UNIT=75, FILE='Enl.dat', ACTION='WRITE' )
+      WRITE(75,*) nfun
+      DO l = 0, lmax
+        IF( info(l+1) /= 0 ) THEN
+          WRITE(6,*) 'ERROR DIAGONALIZING THE MATRIX!', info(l+1)
+          WRITE(6,100) 'l = ', l
+          STOP
+        END IF
+        WRITE(6,100) 'l0 = ', l
+        WRITE(6,110) 'HC = ESC eigenvalue solved'
+        WRITE(6,120) 'n', 'Eigenvalues'
+        WRITE(6,120) '-', '-----------'
+        DO i = 1, nfun
+          IF( i <= 20 ) WRITE(6,200) i+l, En(l*nfun+i)
+          WRITE(75,200) i, En(l*nfun+i)
+        END DO
+        IF( l == l_ini ) THEN
+          WRITE(6,'(/,A29,/)') 'Writing down Initial State WF'
+          rc = bspatom_eigvec(prob, INT(l,C_INT), INT(n0_ini,C_INT), ci)
+          npts = 10000
+          ALLOCATE( r(0:npts), u(0:npts) )
+          IF( rc == 0 ) rc = bspatom_write_wf(prob, ci, INT(npts,C_INT), r, u)
+          IF( rc == -3 ) THEN
+            WRITE(6,*) 'FATAL ERROR - BSPLVB'
+            STOP
+          ELSE IF( rc /= 0 ) THEN
+            WRITE(6,*) 'bsp_atom_host: eigenvector / WRITE_WF failed, code ', rc
+            STOP 1
+          END IF
+          OPEN( UNIT=30, FILE='wf_n0.dat', ACTION='WRITE' )
+          DO i = 0, npts
+            WRITE(30,'(2G20.10)') r(i), u(i)
+          END DO
+          CLOSE(30)
+          DEALLOCATE( r, u )
+        END IF
+      END DO
+      CLOSE(75)
+      CALL bspatom_problem_destroy(prob)
+      WRITE(6,'(/,A17)') 'Program Finished!'
+
+100   FORMAT(/,T2,A5,I2)
+110   FORMAT(T2,A26,/)
+120   FORMAT(T5,A1,T9,A11)
+200   FORMAT(T2,I4,T8,G22.15)
+      END PROGRAM BSP_ATOM_MI355X

@@ -44,6 +44,10 @@ typedef struct bspatom_problem bspatom_problem;   /* opaque */
 /* ---- set-up: READ_INPUTS sizes + GRID + gauleg + SELPOT tables (host), upload ------------- */
 void bspatom_input_defaults(bspatom_input *in);                       /* ReadInputs.f90:27-36,75-84 */
 int bspatom_device_count(void);
+/* Host-only part of the set-up (no GPU needed): sizes as READ_INPUTS derives them; rt[nkp],
+ * aind[2*nfun], xg[ka], wg[ka] as GRID/gauleg build them (call once with NULL arrays for the sizes). */
+int bspatom_host_setup(const bspatom_input *in, bspatom_sizes *s, double *rt, double *aind, double *xg,
+                       double *wg);
 /* Creates the problem on HIP device `device`: derives sizes (ReadInputs.f90:39-141), builds the knot
  * sequence and Aind (grid.f90:14-91), the Gauss-Legendre rule (Modules.f90:112-153) and the
  * potential table (Modules.f90:263-295) on the host, uploads them. */

@@ -132,3 +132,50 @@ def test_bsp_dsygv_symbol(name):
     note("bsp_dsygv_ %s Z^T S Z - I %.2e  residual %.2e" % (name, orth, resid))
     assert orth < 1e-8 and resid < 1e-11
     assert np.max(np.abs(np.triu(U).T @ np.triu(U) - Sf)) < 1e-13
+
+
+def _read_enl(path, nfun, nch):
+    lines = open(path).read().split("\n")
+    assert int(lines[0]) == nfun
+    vals = [float(l.split()[1]) for l in lines[1:] if l.strip()]
+    return np.array(vals).reshape(nch, nfun)
+
+
+@pytest.mark.parametrize("name", ["bsp0", "c1_lin", "rogers"])
+def test_fortran_host_drop_in(tmp_path, name):
+    """bsp_atom_host.x < input: stdout eigenvalue lines, Enl.dat and wf_n0.dat against the reference's."""
+    import subprocess, re
+    exe = os.path.join(ROOT, "bspatom_amd", "bsp_atom_host.x")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran host not built (no flang)")
+    g = load_golden(name)
+    with open(golden_input(name)) as fin:
+        p = subprocess.run([exe], stdin=fin, cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "Program Finished!" in p.stdout
+    nch, nfun = g["E"].shape
+    E = _read_enl(tmp_path / "Enl.dat", nfun, nch)
+    lam = np.max(np.abs(g["E"]))
+    assert np.max(np.abs(E - g["E"])) / lam < 1e-13
+    wf = np.loadtxt(tmp_path / "wf_n0.dat")
+    assert wf.shape == (10001, 2)
+    rows = g["wf_rows"]; idx = g["wf_idx"]
+    sgn = np.sign(np.dot(wf[idx, 1], rows[:, 1]))
+    assert np.max(np.abs(sgn * wf[idx, 1] - rows[:, 1])) <= 2e-8 * np.max(np.abs(rows[:, 1]))
+    # the first-20 table of every channel carries the reference's labels i+l
+    mine = [l for l in p.stdout.split("\n") if re.match(r"^\s+\d+\s+-?\d?\.\d", l)]
+    ref = [l for l in str(g["stdout"]).split("\n") if re.match(r"^\s+\d+\s+-?\d?\.\d", l)]
+    assert len(mine) == len(ref)
+    assert [int(a.split()[0]) for a in mine] == [int(b.split()[0]) for b in ref]
+
+
+def test_python_host_outputs(tmp_path):
+    from bspatom_amd import host
+    g = load_golden("c1_lin")
+    E, c, text = host.run(open(golden_input("c1_lin")).read(), outdir=str(tmp_path))
+    nch, nfun = g["E"].shape
+    Ef = _read_enl(tmp_path / "Enl.dat", nfun, nch)
+    assert np.max(np.abs(Ef - g["E"])) / np.max(np.abs(g["E"])) < 1e-13
+    wf = np.loadtxt(tmp_path / "wf_n0.dat")
+    assert wf.shape == (10001, 2)
+    assert "Program Finished!" in text
