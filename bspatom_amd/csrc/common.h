@@ -39,6 +39,11 @@ struct GemmDesc {
     int lower_only;   // 1: C is square/symmetric, compute only tiles touching i >= j (col-major C)
 };
 int gemm_f64(const GemmDesc &g, hipStream_t st);
+// pipelined, symmetry-aware products of sy2sb (see gemm_f64.hip)
+int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const double *buf, long ldb, long bsBuf,
+                    hipStream_t st);
+int symm_lower_f64(int m, int batch, const double *A22, long ld, long bsA, const double *W, long ldw, long bsW,
+                   double *Y, long ldy, long bsY, hipStream_t st);
 
 // ---- stage kernels (launchers) -------------------------------------------------------------
 // assemble.hip

@@ -172,4 +172,195 @@ int gemm_f64(const GemmDesc &gin, hipStream_t st)
     return launch_cfg<64, 64, 2, 2>(g, alay, blay, st);
 }
 
+
+// ================================================================================================
+// Pipelined kernels for the two big products of sy2sb (per panel):
+//   MODE 1 "syr2k": A22 -= [V Z] [Z V]^T     (K = 128)
+//   MODE 2 "symm" : Y = A22 W                 (K = m)
+// Both work on A22 in column-major storage of which only the 64x64 blocks (I, J) with J <= I+1
+// (lower triangle + first block super-diagonal) are kept valid: MODE 1 skips every 128x128 tile
+// whose column block is more than one above its row block (45% of the flops and of the HBM traffic
+// of the full update are saved), MODE 2 reads the invalid part through the transposed address.
+// The invariant survives the 64-row shift of the trailing matrix from panel to panel because it is
+// stated in 64-blocks while the tiles are 128 wide (derivation in DESIGN.md section 4).
+//
+// Pipeline per K-step (BK = 16): global loads of step t+1 go to registers before the MFMAs of
+// step t; they are written to the other LDS buffer after the MFMAs; one LDS-only barrier per step.
+// With beta != 0 the C tile is loaded straight into the accumulators ((beta/alpha) C) while the
+// first tiles are staged, so the epilogue is a pure store.
+// ================================================================================================
+__device__ __forceinline__ void lds_barrier2() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// tile staging: element (x, k) of an X-by-K operand; LAY 0: contiguous along x, stride sk along k;
+// LAY 1: contiguous along k, stride sx along x.  NR = double2 registers per thread.
+template <int BX, int LAY>
+__device__ __forceinline__ void tile_load(double2 (&r)[BK * BX / 512], const double *__restrict__ base, long sx,
+                                          long sk, int x0, int k0, int X, int K, int tid)
+{
+#pragma unroll
+    for (int it = 0; it < BK * BX / 512; ++it) {
+        const int idx = tid + it * 256;
+        if (LAY == 0) {
+            const int kk = idx / (BX / 2), xx = (idx % (BX / 2)) * 2;
+            const int gx = x0 + xx, gk = k0 + kk;
+            const bool ok = (gk < K) && (gx + 1 < X);
+            const double2 v = *reinterpret_cast<const double2 *>(base + (ok ? ((long)gx + (long)gk * sk) : 0));
+            r[it] = ok ? v : make_double2(0.0, 0.0);
+        } else {
+            const int xx = idx / (BK / 2), kk = (idx % (BK / 2)) * 2;
+            const int gx = x0 + xx, gk = k0 + kk;
+            const bool ok = (gx < X) && (gk + 1 < K);
+            const double2 v = *reinterpret_cast<const double2 *>(base + (ok ? ((long)gx * sx + (long)gk) : 0));
+            r[it] = ok ? v : make_double2(0.0, 0.0);
+        }
+    }
+}
+
+template <int BX, int LAY>
+__device__ __forceinline__ void tile_store(const double2 (&r)[BK * BX / 512], double *S, int tid)
+{
+    constexpr int LD = BX + 16;
+#pragma unroll
+    for (int it = 0; it < BK * BX / 512; ++it) {
+        const int idx = tid + it * 256;
+        if (LAY == 0) {
+            const int kk = idx / (BX / 2), xx = (idx % (BX / 2)) * 2;
+            *reinterpret_cast<double2 *>(&S[kk * LD + xx]) = r[it];
+        } else {
+            const int xx = idx / (BK / 2), kk = (idx % (BK / 2)) * 2;
+            S[kk * LD + xx] = r[it].x;
+            S[(kk + 1) * LD + xx] = r[it].y;
+        }
+    }
+}
+
+// kernel view: C'(i', j') with j' memory-contiguous (sCn == 1 required).
+template <int BM, int BN, int ALAY, int BLAY, int MODE>
+__global__ __launch_bounds__(256) void gemm2_kernel(GemmDesc g)
+{
+    constexpr int WM = 2, WN = 2;
+    constexpr int LDA = BM + 16, LDB = BN + 16;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    __shared__ double As[2][BK * LDA];
+    __shared__ double Bs[2][BK * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (MODE == 1 && (int)blockIdx.y > (int)blockIdx.x + 1) return;     // column block > row block + 1
+    const double *A = g.A + (long)blockIdx.z * g.bA;
+    const double *B = g.B + (long)blockIdx.z * g.bB;
+    double *C = g.C + (long)blockIdx.z * g.bC;
+    const double alpha = g.alpha, beta = g.beta;
+
+    double2 ra[BK * BM / 512], rb[BK * BN / 512];
+    // MODE 2: B is the symmetric A22; K-steps beyond the diagonal block of this row tile read A22^T
+    const int ksw = (MODE == 2) ? (n0 + 128) : 0x7fffffff;
+    auto loadB = [&](int k0) {
+        if (MODE == 2 && k0 >= ksw) tile_load<BN, 1>(rb, B, g.sBk, 1, n0, k0, g.N, g.K, tid);   // A22(k,i): stride ld along i
+        else tile_load<BN, BLAY>(rb, B, g.sBn, g.sBk, n0, k0, g.N, g.K, tid);
+    };
+    auto storeB = [&](int k0, double *S) {
+        if (MODE == 2 && k0 >= ksw) tile_store<BN, 1>(rb, S, tid);
+        else tile_store<BN, BLAY>(rb, S, tid);
+    };
+    tile_load<BM, ALAY>(ra, A, g.sAm, g.sAk, m0, 0, g.M, g.K, tid);
+    loadB(0);
+
+    double4_t acc[TM][TN];
+    if (beta != 0.0) {
+        const double sc = beta / alpha;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gi = m0 + wm * (BM / WM) + i * 16 + (lane >> 4) + 4 * r;
+                    const int gj = n0 + wn * (BN / WN) + j * 16 + (lane & 15);
+                    const bool ok = (gi < g.M && gj < g.N);
+                    const double v = C[ok ? ((long)gi * g.sCm + (long)gj) : 0];
+                    acc[i][j][r] = ok ? sc * v : 0.0;
+                }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    }
+    tile_store<BM, ALAY>(ra, As[0], tid);
+    storeB(0, Bs[0]);
+    lds_barrier2();
+
+    const int nk = (g.K + BK - 1) / BK;
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) {
+            tile_load<BM, ALAY>(ra, A, g.sAm, g.sAk, m0, (t + 1) * BK, g.M, g.K, tid);
+            loadB((t + 1) * BK);
+        }
+#pragma unroll
+        for (int k4 = 0; k4 < BK / 4; ++k4) {
+            const int kr = k4 * 4 + (lane >> 4);
+            double a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[cur][kr * LDA + wm * (BM / WM) + i * 16 + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[cur][kr * LDB + wn * (BN / WN) + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nk) {
+            tile_store<BM, ALAY>(ra, As[cur ^ 1], tid);
+            storeB((t + 1) * BK, Bs[cur ^ 1]);
+        }
+        lds_barrier2();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = m0 + wm * (BM / WM) + i * 16 + (lane >> 4) + 4 * r;
+                const int gj = n0 + wn * (BN / WN) + j * 16 + (lane & 15);
+                if (gi < g.M && gj < g.N) C[(long)gi * g.sCm + (long)gj] = alpha * acc[i][j][r];
+            }
+}
+
+// A22 (m x m, column-major, ld) -= P Q^T with P = buf[:, 0:128], Q = buf[:, 64:192] (ldb rows apart),
+// only tiles with column block <= row block + 1.
+int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const double *buf, long ldb, long bsBuf,
+                    hipStream_t st)
+{
+    GemmDesc g{};
+    g.M = m; g.N = m; g.K = 128; g.batch = batch;
+    g.A = buf + 64 * ldb; g.sAm = 1; g.sAk = ldb; g.bA = bsBuf;      // kernel-A(i'=c, k) = Q(c, k)
+    g.B = buf; g.sBn = 1; g.sBk = ldb; g.bB = bsBuf;                  // kernel-B(k, j'=r) = P(r, k)
+    g.C = A22; g.sCm = ld; g.sCn = 1; g.bC = bsA;                     // C'(c, r) = A22(r, c)
+    g.alpha = -1.0; g.beta = 1.0; g.lower_only = 0;
+    dim3 grid((m + 127) / 128, (m + 127) / 128, batch);
+    hipLaunchKernelGGL((gemm2_kernel<128, 128, 0, 0, 1>), grid, dim3(256), 0, st, g);
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
+
+// Y (m x 64, column-major, ldy) = A22 W, A22 valid on 64-blocks (I, J) with J <= I+1, W m x 64 (ldw).
+int symm_lower_f64(int m, int batch, const double *A22, long ld, long bsA, const double *W, long ldw, long bsW,
+                   double *Y, long ldy, long bsY, hipStream_t st)
+{
+    GemmDesc g{};
+    g.M = 64; g.N = m; g.K = m; g.batch = batch;
+    g.A = W; g.sAm = ldw; g.sAk = 1; g.bA = bsW;                      // kernel-A(i'=c, k) = W(k, c)
+    g.B = A22; g.sBn = 1; g.sBk = ld; g.bB = bsA;                     // kernel-B(k, j'=i) = A22(i, k) (direct part)
+    g.C = Y; g.sCm = ldy; g.sCn = 1; g.bC = bsY;                      // C'(c, i) = Y(i, c)
+    g.alpha = 1.0; g.beta = 0.0; g.lower_only = 0;
+    dim3 grid((m + 127) / 128, 1, batch);
+    hipLaunchKernelGGL((gemm2_kernel<64, 128, 1, 0, 2>), grid, dim3(256), 0, st, g);
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
+
 }  // namespace bsp

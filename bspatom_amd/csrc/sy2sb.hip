@@ -301,6 +301,8 @@ int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipS
 {
     if (nb != NB || npad % NB != 0) return BSP_ERR_ARG;
     if (npad - NB > PQ_THREADS * 16) return BSP_ERR_UNSUPPORTED;   // n <= 8256
+    static int g_sym = -1;      // BSP_SY2SB_SYM=0 selects the plain full-storage GEMMs (A/B testing)
+    if (g_sym < 0) { const char *e = getenv("BSP_SY2SB_SYM"); g_sym = e ? atoi(e) : 1; }
     const long ld = npad;
     const long bsA = (long)npad * npad, bsBuf = (long)npad * 3 * NB, bsW = (long)npad * NB, bsS = NB * NB;
     for (int c0 = 0; c0 + NB < npad; c0 += NB) {
@@ -329,13 +331,17 @@ int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipS
         g.B = w.T; g.sBk = 1; g.sBn = NB; g.bB = bsS;
         g.C = w.W; g.sCm = 1; g.sCn = npad; g.bC = bsW; g.alpha = 1.0; g.beta = 0.0;
         if ((rc = gemm_f64(g, st))) return rc;
-        // Y = A22 W  -> buf[:, NB:2NB]
+        // Y = A22 W  -> buf[:, NB:2NB]   (A22 valid on 64-blocks J <= I+1 only)
         double *A22 = d_A + (size_t)r0 * ld + r0;
-        g.M = m; g.N = NB; g.K = m;
-        g.A = A22; g.sAm = 1; g.sAk = ld; g.bA = bsA;
-        g.B = w.W; g.sBk = 1; g.sBn = npad; g.bB = bsW;
-        g.C = w.buf + (size_t)NB * npad; g.sCm = 1; g.sCn = npad; g.bC = bsBuf; g.alpha = 1.0; g.beta = 0.0;
-        if ((rc = gemm_f64(g, st))) return rc;
+        if (g_sym) {
+            if ((rc = symm_lower_f64(m, batch, A22, ld, bsA, w.W, npad, bsW, w.buf + (size_t)NB * npad, npad, bsBuf, st))) return rc;
+        } else {
+            g.M = m; g.N = NB; g.K = m;
+            g.A = A22; g.sAm = 1; g.sAk = ld; g.bA = bsA;
+            g.B = w.W; g.sBk = 1; g.sBn = npad; g.bB = bsW;
+            g.C = w.buf + (size_t)NB * npad; g.sCm = 1; g.sCn = npad; g.bC = bsBuf; g.alpha = 1.0; g.beta = 0.0;
+            if ((rc = gemm_f64(g, st))) return rc;
+        }
         // K = W^T Y
         g.M = NB; g.N = NB; g.K = m;
         g.A = w.W; g.sAm = npad; g.sAk = 1; g.bA = bsW;
@@ -349,11 +355,15 @@ int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipS
         g.C = w.buf + (size_t)NB * npad; g.sCm = 1; g.sCn = npad; g.bC = bsBuf; g.alpha = -0.5; g.beta = 1.0;
         if ((rc = gemm_f64(g, st))) return rc;
         // A22 -= [V Z] [Z V]^T
-        g.M = m; g.N = m; g.K = 2 * NB;
-        g.A = w.buf; g.sAm = 1; g.sAk = npad; g.bA = bsBuf;
-        g.B = w.buf + (size_t)NB * npad; g.sBk = npad; g.sBn = 1; g.bB = bsBuf;
-        g.C = A22; g.sCm = 1; g.sCn = ld; g.bC = bsA; g.alpha = -1.0; g.beta = 1.0;
-        if ((rc = gemm_f64(g, st))) return rc;
+        if (g_sym) {
+            if ((rc = syr2k_lower_f64(m, batch, A22, ld, bsA, w.buf, npad, bsBuf, st))) return rc;
+        } else {
+            g.M = m; g.N = m; g.K = 2 * NB;
+            g.A = w.buf; g.sAm = 1; g.sAk = npad; g.bA = bsBuf;
+            g.B = w.buf + (size_t)NB * npad; g.sBk = npad; g.sBn = 1; g.bB = bsBuf;
+            g.C = A22; g.sCm = 1; g.sCn = ld; g.bC = bsA; g.alpha = -1.0; g.beta = 1.0;
+            if ((rc = gemm_f64(g, st))) return rc;
+        }
     }
     return BSP_OK;
 }
