@@ -163,7 +163,7 @@ static int ensure_capacity(bspatom_problem *p, int nl)
     BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_rdiag), n * sizeof(double)));
     BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_Y), b * np * np * sizeof(double)));
     BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_C), b * np * np * sizeof(double)));
-    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_AB), b * np * 128 * sizeof(double)));
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_AB), b * ab_stride((int)np) * sizeof(double)));
     BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_d), b * np * sizeof(double)));
     BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_e), b * np * sizeof(double)));
     BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_E), b * n * sizeof(double)));
@@ -404,7 +404,7 @@ extern "C" int bspatom_stage_sy2sb(int npad, int batch, const double *A, double 
     if ((rc = need_gpu())) return rc;
     if (npad % 64) return BSP_ERR_ARG;
     DevBuf dA, dAB;
-    if ((rc = dA.put(A, (size_t)batch * npad * npad)) || (rc = dAB.alloc((size_t)batch * npad * 128))) return rc;
+    if ((rc = dA.put(A, (size_t)batch * npad * npad)) || (rc = dAB.alloc((size_t)batch * ab_stride(npad)))) return rc;
     void *work = nullptr;
     BSP_HIP(hipMalloc(&work, sy2sb_work_bytes(npad, 64, batch)));
     Sy2sbWork w;
@@ -415,7 +415,10 @@ extern "C" int bspatom_stage_sy2sb(int npad, int batch, const double *A, double 
     hipFree(work);
     if (rc) return rc;
     BSP_HIP(e);
-    return dAB.get(AB, (size_t)batch * npad * 128);
+    for (int b = 0; b < batch; ++b)      // host layout is dense [batch][npad][128]
+        BSP_HIP(hipMemcpy(AB + (size_t)b * npad * 128, dAB.p + b * ab_stride(npad), (size_t)npad * 128 * sizeof(double),
+                          hipMemcpyDeviceToHost));
+    return BSP_OK;
 }
 
 extern "C" int bspatom_stage_sb2st(int n, int npad, int batch, const double *AB, double *d, double *e)
@@ -423,7 +426,11 @@ extern "C" int bspatom_stage_sb2st(int n, int npad, int batch, const double *AB,
     int rc;
     if ((rc = need_gpu())) return rc;
     DevBuf dAB, dd, de;
-    if ((rc = dAB.put(AB, (size_t)batch * npad * 128)) || (rc = dd.alloc((size_t)batch * npad)) ||
+    if ((rc = dAB.alloc((size_t)batch * ab_stride(npad)))) return rc;
+    for (int b = 0; b < batch; ++b)
+        BSP_HIP(hipMemcpy(dAB.p + b * ab_stride(npad), AB + (size_t)b * npad * 128, (size_t)npad * 128 * sizeof(double),
+                          hipMemcpyHostToDevice));
+    if ((rc = dd.alloc((size_t)batch * npad)) ||
         (rc = de.alloc((size_t)batch * npad))) return rc;
     if ((rc = launch_sb2st(n, npad, 64, batch, dAB.p, dd.p, de.p, 0))) return rc;
     BSP_HIP(hipDeviceSynchronize());

@@ -25,6 +25,11 @@
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// Batch stride (doubles) of the band storage AB[npad][128] of one l-channel.  The 1088-double
+// (8.5 KiB) skew keeps the channels, which march through their bands in lock-step during sb2st, from
+// hitting the same HBM channel/bank at the same instant (a power-of-two stride would).
+__host__ __device__ inline size_t ab_stride(int npad) { return (size_t)npad * 128 + 1088; }
+
 namespace bsp {
 
 // ---- batched fp64 MFMA GEMM: C[b] = alpha * A[b] * B[b] + beta * C[b] ----------------------

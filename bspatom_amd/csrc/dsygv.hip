@@ -69,7 +69,7 @@ extern "C" void bsp_dsygv_(const int *itype, const char *jobz, const char *uplo,
     const size_t nn = (size_t)npad * npad;
     bool ok = dSB.alloc((size_t)k * n) == hipSuccess && dHB.alloc((size_t)k * n) == hipSuccess &&
               dUB.alloc((size_t)k * n) == hipSuccess && dr.alloc(n) == hipSuccess && dY.alloc(nn) == hipSuccess &&
-              dC.alloc(nn) == hipSuccess && dAB.alloc((size_t)npad * 128) == hipSuccess &&
+              dC.alloc(nn) == hipSuccess && dAB.alloc(ab_stride(npad)) == hipSuccess &&
               dd.alloc(npad) == hipSuccess && de.alloc(npad) == hipSuccess && dE.alloc(n) == hipSuccess &&
               dwork.alloc(sy2sb_work_bytes(npad, 64, 1)) == hipSuccess && dinfo.alloc(1) == hipSuccess;
     if (!ok) { *info = -98; return; }

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void sb2st_kernel(int n, int npad, double *ABa
     constexpr int LD = 2 * SB;
     const int tid = threadIdx.x, i = tid & 63, part = tid >> 6;
     const size_t ch = blockIdx.x;
-    double *AB = ABall + ch * (size_t)npad * LD;
+    double *AB = ABall + ch * ab_stride(npad);
 
     for (int s = 0; s < n - 2; ++s) {
         int L = (n - 1 - s < SB) ? (n - 1 - s) : SB;
@@ -210,18 +210,40 @@ __global__ __launch_bounds__(256) void sb2st_kernel(int n, int npad, double *ABa
 // covers them.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Wave-wide sum, result uniform in every lane: DPP row scan (row_shr 1,2,4,8 -> lane 15 of each
+// 16-lane row holds the row total) + four readlanes.  ~10x shorter dependent chain than a
+// ds_bpermute butterfly, which matters because the reflector construction is serial.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, 0xf, 0xf, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, 0xf, 0xf, true);
+    return r.d;
+}
+__device__ __forceinline__ double read_lane(double x, int l)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_readlane(u.i[0], l);
+    r.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+    return r.d;
+}
 __device__ __forceinline__ double wave_sum(double x)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
-    return x;
+    x += dpp_mov<0x111>(x);      // row_shr:1
+    x += dpp_mov<0x112>(x);      // row_shr:2
+    x += dpp_mov<0x114>(x);      // row_shr:4
+    x += dpp_mov<0x118>(x);      // row_shr:8
+    return (read_lane(x, 15) + read_lane(x, 31)) + (read_lane(x, 47) + read_lane(x, 63));
 }
 
 // lane-parallel dlarfg on one wavefront: xi = element i of x (0 beyond L).  Returns v_i.
 __device__ __forceinline__ double wave_house(double xi, int lane, int L, double *beta, double *tau)
 {
     const double sq = wave_sum((lane >= 1 && lane < L) ? xi * xi : 0.0);
-    const double alpha = __shfl(xi, 0);
+    const double alpha = read_lane(xi, 0);
     double scale;
     if (!(alpha * alpha + sq > 1e-280) || sq == 0.0) { *beta = alpha; *tau = 0.0; scale = 0.0; }
     else {
@@ -244,7 +266,7 @@ __global__ __launch_bounds__(256) void sb2st_kernel_v2(int n, int npad, double *
     constexpr int LD = 2 * SB;
     const int tid = threadIdx.x, i = tid & 63, part = tid >> 6;
     const size_t ch = blockIdx.x;
-    double *AB = ABall + ch * (size_t)npad * LD;
+    double *AB = ABall + ch * ab_stride(npad);
 
     for (int s = 0; s < n - 2; ++s) {
         int L = (n - 1 - s < SB) ? (n - 1 - s) : SB;
@@ -399,12 +421,368 @@ __global__ __launch_bounds__(256) void sb2st_kernel_v2(int n, int npad, double *
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// v3: register-blocked tiles.  Thread (bi, bj) of the 16 x 16 thread grid owns the 4 x 4 sub-blocks
+// rows 4bi.., cols 4bj.. of the current B and D2 tiles AND of the prefetched next ones, all in
+// registers; LDS carries only the vectors (vc, vn, w, z, p) and the 16-way partial sums of the
+// matrix-vector products, which the finalising wavefront adds up.  4 LDS-only barriers per step:
+//   P1 all    : issue the loads of the next step's tiles; partial w0 = B vc          -> R1[bj][i]
+//   P2 wave 0 : w = tau sum R1 ; x' = B(:,0) - w vc_0 ; (vn, tau2, beta2) ; s = vn^T w
+//   P3 all    : partial z0 = vn^T B -> R2[bi][j] ; partial p0 = D2 vn -> R3[bj][i] (row part),
+//               R4[bi][j] (column part of the strictly-lower sub-blocks)
+//   P4 wave 0 : z = tau2 (sum R2 - s vc)        wave 1 : p = tau2 (sum R3 + sum R4) + alpha vn
+//   P5 all    : B, D2 updated in registers and stored; next tiles become current (no copy: the
+//               step function is instantiated twice with the register sets swapped).
+constexpr int RLD = SB + 4;     // row stride of the partial-sum arrays (bank spread)
+
+struct ChaseState { int r0, L, L2, L3; double tau; };
+
+// thread (ib, jb): rows ib + 16 ri (ri < 4), columns 4 jb + cj (cj < 4).  For a fixed (ri, cj) the 16
+// lanes of a DPP row cover 16 consecutive rows of one column = one full 128-B line, so a wave-level
+// load/store touches 4 whole lines (the 4x4 contiguous sub-block variant touched 16 partial ones and
+// was bound by the CU's address unit).
+#define SB3_ROW(ri) (ib + 16 * (ri))
+#define SB3_COL(cj) (j0 + (cj))
+// Element (i, j) of a tile whose top-left element sits at AB[base] lives at base + j*(LD-1) + i
+// (B: base = r0*LD + L, D2: base = rn*LD): per-thread constants off[ri][cj], a wave-uniform base per
+// step.  `low` bit (ri*4+cj) marks i >= j (D2 is kept as a lower triangle).  Branch-free: masked lanes
+// read element 0 of the tile and discard it.
+__device__ __forceinline__ void load_tiles(const double *__restrict__ AB, int r0, int L, int L2, int ib, int j0,
+                                           const unsigned (&off)[4][4], unsigned low,
+                                           double (&Bq)[4][4], double (&Dq)[4][4])
+{
+    constexpr int LD = 2 * SB;
+    const double *__restrict__ Bb = AB + ((size_t)r0 * LD + L);
+    const double *__restrict__ Db = AB + (size_t)(r0 + L) * LD;
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            const int i = SB3_ROW(ri), j = SB3_COL(cj);
+            const bool okb = (i < L2 && j < L);
+            const bool okd = ((low >> (ri * 4 + cj)) & 1u) && (i < L2);
+            const double bv = Bb[okb ? off[ri][cj] : 0u];
+            const double dv = Db[okd ? off[ri][cj] : 0u];
+            Bq[ri][cj] = okb ? bv : 0.0;
+            Dq[ri][cj] = okd ? dv : 0.0;
+        }
+}
+
+struct Sb3Lds {
+    double va[SB], vb[SB], w[SB], z[SB], pv[SB], x0[SB];
+    double R1[16][RLD], R2[16][RLD], R3[16][RLD], R4[16][RLD];
+    double sc[8];
+};
+
+// diagnostic cycle stamps (DIAG instantiation only; never part of a timed or shipped run)
+#define SB3_STAMP(k)                                                             \
+    if (DIAG) {                                                                  \
+        const long long tnow_ = (long long)__builtin_amdgcn_s_memtime();         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       \
+        acc[k] += tnow_ - tlast;                                                 \
+        tlast = tnow_;                                                           \
+    }
+
+// one chase step; (Bc, Dc) current tiles, (Bn, Dn) receive the prefetch of the next step
+template <bool DIAG>
+__device__ __forceinline__ void chase_step(double *__restrict__ AB, Sb3Lds &S, const double *vc, double *vn,
+                                           ChaseState &st, int n, int tid, int ib, int j0,
+                                           const unsigned (&off)[4][4], unsigned low,
+                                           double (&Bc)[4][4], double (&Dc)[4][4], double (&Bn)[4][4], double (&Dn)[4][4],
+                                           long long (&acc)[12], long long &tlast)
+{
+    constexpr int LD = 2 * SB;
+    const int jb = j0 >> 2;
+    const int r0 = st.r0, L = st.L, L2 = st.L2, rn = r0 + L;
+    const bool have_next = (rn + L2 < n);
+    const int L3 = have_next ? ((n - (rn + L2) < SB) ? (n - (rn + L2)) : SB) : 0;
+    // ---- P1 ----
+    SB3_STAMP(0)
+    // Prefetch of the next step's tiles: ONE branch-free masked loader.  Any control flow around these
+    // loads (even wave-uniform) makes hipcc drain vmcnt(0) where the register results join, which
+    // serialises the whole prefetch (measured 2.2x slower).  Without a next step the bases are clamped to
+    // AB and every lane is masked off.
+    {
+        const double *__restrict__ Bb = have_next ? (AB + ((size_t)rn * LD + L2)) : AB;
+        const double *__restrict__ Db = have_next ? (AB + (size_t)(rn + L2) * LD) : AB;
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const int i = SB3_ROW(ri), j = SB3_COL(cj);
+                const bool okb = (i < L3) && (j < L2);
+                const bool okd = ((low >> (ri * 4 + cj)) & 1u) && (i < L3);
+                const double bv = Bb[okb ? off[ri][cj] : 0u];
+                const double dv = Db[okd ? off[ri][cj] : 0u];
+                Bn[ri][cj] = okb ? bv : 0.0;
+                Dn[ri][cj] = okd ? dv : 0.0;
+            }
+    }
+    SB3_STAMP(1)
+    {
+        double vcj[4];
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) vcj[cj] = vc[j0 + cj];
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            double a = 0.0;
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj) a += Bc[ri][cj] * vcj[cj];
+            S.R1[jb][SB3_ROW(ri)] = a;
+        }
+        if (jb == 0) {
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) S.x0[SB3_ROW(ri)] = Bc[ri][0];
+        }
+    }
+    SB3_STAMP(2)
+    lds_barrier();
+    SB3_STAMP(3)
+    // ---- P2: wave 0 ----
+    if (tid < 64) {
+        const int i = tid;
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += S.R1[q][i];
+        const double wi = st.tau * a;
+        const double xi = (i < L2) ? (S.x0[i] - wi * vc[0]) : 0.0;
+        double beta2, tau2;
+        const double vi = wave_house(xi, i, L2, &beta2, &tau2);
+        const double sdot = wave_sum(vi * wi);
+        S.w[i] = wi; vn[i] = vi;
+        if (i == 0) { S.sc[1] = beta2; S.sc[2] = tau2; S.sc[3] = sdot; }
+    }
+    SB3_STAMP(4)
+    lds_barrier();
+    SB3_STAMP(5)
+    const double beta2 = S.sc[1], tau2 = S.sc[2], sdot = S.sc[3];
+    // ---- P3 ----
+    double vni[4], vnj[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { vni[x] = vn[SB3_ROW(x)]; vnj[x] = vn[j0 + x]; }
+    {
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+            double a = 0.0;
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) a += vni[ri] * Bc[ri][cj];
+            S.R2[ib][j0 + cj] = a;
+        }
+        // D2 vn: sub-blocks with bi >= bj give the row part; strictly lower ones also the column part
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            double a = 0.0;
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj) a += Dc[ri][cj] * vnj[cj];          // Dc is zero above the diagonal
+            S.R3[jb][SB3_ROW(ri)] = a;
+        }
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+            double a = 0.0;
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) a += (SB3_ROW(ri) != j0 + cj) ? Dc[ri][cj] * vni[ri] : 0.0;   // strictly lower
+            S.R4[ib][j0 + cj] = a;
+        }
+    }
+    SB3_STAMP(6)
+    lds_barrier();
+    SB3_STAMP(7)
+    // ---- P4 ----
+    if (tid < 64) {
+        const int j = tid;
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += S.R2[q][j];
+        S.z[j] = tau2 * (a - sdot * vc[j]);
+    } else if (tid < 128) {
+        const int i = tid - 64;
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += S.R3[q][i] + S.R4[q][i];
+        const double pi = tau2 * a;
+        const double dot = wave_sum(pi * vn[i]);
+        S.pv[i] = pi + (-0.5 * tau2 * dot) * vn[i];
+    }
+    SB3_STAMP(8)
+    lds_barrier();
+    SB3_STAMP(9)
+    // ---- P5 ----
+    {
+        double wi[4], zj[4], vcj[4], pi[4], pj[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            wi[x] = S.w[SB3_ROW(x)]; zj[x] = S.z[j0 + x]; vcj[x] = vc[j0 + x]; pi[x] = S.pv[SB3_ROW(x)]; pj[x] = S.pv[j0 + x];
+        }
+        double *__restrict__ Bb = AB + ((size_t)r0 * LD + L);
+        double *__restrict__ Db = AB + (size_t)rn * LD;
+        if (L == SB && L2 == SB) {
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri) {
+                    double bnew = Bc[ri][cj] - (wi[ri] * vcj[cj] + vni[ri] * zj[cj]);
+                    if (cj == 0 && j0 == 0) bnew = (SB3_ROW(ri) == 0) ? beta2 : 0.0;
+                    Bb[off[ri][cj]] = bnew;
+                    if ((low >> (ri * 4 + cj)) & 1u)
+                        Db[off[ri][cj]] = Dc[ri][cj] - (vni[ri] * pj[cj] + pi[ri] * vnj[cj]);
+                }
+        } else {
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri) {
+                    const int i = SB3_ROW(ri), j = j0 + cj;
+                    double bnew = Bc[ri][cj] - (wi[ri] * vcj[cj] + vni[ri] * zj[cj]);
+                    if (j == 0) bnew = (i == 0) ? beta2 : 0.0;
+                    if (i < L2 && j < L) Bb[off[ri][cj]] = bnew;
+                    if (((low >> (ri * 4 + cj)) & 1u) && i < L2)
+                        Db[off[ri][cj]] = Dc[ri][cj] - (vni[ri] * pj[cj] + pi[ri] * vnj[cj]);
+                }
+        }
+    }
+    SB3_STAMP(10)
+    st.r0 = rn; st.L = L2; st.L2 = L3; st.tau = tau2;
+}
+
+template <bool DIAG>
+__global__ __launch_bounds__(256) void sb2st_kernel_v3(int n, int npad, double *ABall, double *dall, double *eall,
+                                                      long long *diag)
+{
+    long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = DIAG ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    __shared__ Sb3Lds S;
+    constexpr int LD = 2 * SB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ib = lane & 15, jb = (lane >> 4) + 4 * wave;
+    const int j0 = 4 * jb;
+    unsigned off[4][4], low = 0;
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            const int i = SB3_ROW(ri), j = j0 + cj;
+            off[ri][cj] = (unsigned)(j * (LD - 1) + i);
+            if (i >= j) low |= 1u << (ri * 4 + cj);
+        }
+    const size_t ch = blockIdx.x;
+    double *AB = ABall + ch * ab_stride(npad);
+    double B0[4][4], D0[4][4], B1[4][4], D1[4][4];
+
+    for (int s = 0; s < n - 2; ++s) {
+        int L = (n - 1 - s < SB) ? (n - 1 - s) : SB;
+        if (L < 2) break;
+        const int r0 = s + 1;
+        __syncthreads();          // HBM stores of the previous sweep are visible to every wave
+        // ---- sweep start: D = A[r0:r0+L, r0:r0+L] (as a "D2" at rn = r0 with an empty B) ----
+        {
+            // load_tiles with (r0' = r0 - 0, L' = 0): B part masked out (j < 0 never), D2 at rn = r0
+            load_tiles(AB, r0, 0, L, ib, j0, off, low, B0, D0);
+        }
+        if (tid < 64) {
+            const double xraw = AB[(tid < L) ? ((size_t)s * LD + 1 + tid) : 0];
+            const double xi = (tid < L) ? xraw : 0.0;
+            double beta, tau;
+            const double vi = wave_house(xi, tid, L, &beta, &tau);
+            S.va[tid] = vi;
+            if (tid < L) AB[(size_t)s * LD + 1 + tid] = (tid == 0) ? beta : 0.0;
+            if (tid == 0) S.sc[0] = tau;
+        }
+        lds_barrier();
+        const double tau0 = S.sc[0];
+        double vni[4], vnj[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { vni[x] = S.va[SB3_ROW(x)]; vnj[x] = S.va[j0 + x]; }
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            double a = 0.0;
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj) a += D0[ri][cj] * vnj[cj];
+            S.R3[jb][SB3_ROW(ri)] = a;
+        }
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+            double a = 0.0;
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) a += (SB3_ROW(ri) != j0 + cj) ? D0[ri][cj] * vni[ri] : 0.0;
+            S.R4[ib][j0 + cj] = a;
+        }
+        lds_barrier();
+        if (tid < 64) {
+            const int i = tid;
+            double a = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a += S.R3[q][i] + S.R4[q][i];
+            const double pi = tau0 * a;
+            const double dot = wave_sum(pi * S.va[i]);
+            S.pv[i] = pi + (-0.5 * tau0 * dot) * S.va[i];
+        }
+        lds_barrier();
+        {
+            double pi[4], pj[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { pi[x] = S.pv[SB3_ROW(x)]; pj[x] = S.pv[j0 + x]; }
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri) {
+                    const int i = SB3_ROW(ri);
+                    if (((low >> (ri * 4 + cj)) & 1u) && i < L)
+                        AB[(size_t)r0 * LD + off[ri][cj]] = D0[ri][cj] - (vni[ri] * pj[cj] + pi[ri] * vnj[cj]);
+                }
+        }
+        // ---- chase ----
+        ChaseState st;
+        st.r0 = r0; st.L = L; st.tau = tau0;
+        st.L2 = (r0 + L < n) ? ((n - (r0 + L) < SB) ? (n - (r0 + L)) : SB) : 0;
+        if (st.L2 > 0) load_tiles(AB, r0, L, st.L2, ib, j0, off, low, B0, D0);
+        double *vc = S.va, *vn = S.vb;
+        if (DIAG) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); acc[11] += t_ - tlast; tlast = t_; }
+        while (st.L2 > 0) {
+            chase_step<DIAG>(AB, S, vc, vn, st, n, tid, ib, j0, off, low, B0, D0, B1, D1, acc, tlast);
+            if (st.L2 <= 0) break;
+            chase_step<DIAG>(AB, S, vn, vc, st, n, tid, ib, j0, off, low, B1, D1, B0, D0, acc, tlast);
+        }
+    }
+    if (DIAG && (tid & 63) == 0 && blockIdx.x == 0) {
+        for (int q = 0; q < 12; ++q) diag[(tid >> 6) * 12 + q] = acc[q];
+    }
+    __syncthreads();
+    double *d = dall + ch * (size_t)npad, *e = eall + ch * (size_t)npad;
+    for (int j = tid; j < n; j += 256) {
+        d[j] = AB[(size_t)j * LD];
+        e[j] = (j < n - 1) ? AB[(size_t)j * LD + 1] : 0.0;
+    }
+}
+
 int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st)
 {
     if (b != SB) return BSP_ERR_ARG;
     static int ver = -1;
-    if (ver < 0) { const char *e = getenv("BSP_SB2ST_VERSION"); ver = e ? atoi(e) : 2; }
+    if (ver < 0) { const char *e = getenv("BSP_SB2ST_VERSION"); ver = e ? atoi(e) : 3; }
     if (ver == 1) hipLaunchKernelGGL(sb2st_kernel, dim3(batch), dim3(256), 0, st, n, npad, d_AB, d_d, d_e);
+    else if (ver == 3) {
+        static int diag = -1;
+        if (diag < 0) { const char *e = getenv("BSP_SB2ST_DIAG"); diag = e ? atoi(e) : 0; }
+        if (!diag) hipLaunchKernelGGL(sb2st_kernel_v3<false>, dim3(batch), dim3(256), 0, st, n, npad, d_AB, d_d, d_e, (long long *)nullptr);
+        else {
+            long long *dbuf = nullptr, h[48];
+            BSP_HIP(hipMalloc(reinterpret_cast<void **>(&dbuf), sizeof(h)));
+            hipLaunchKernelGGL(sb2st_kernel_v3<true>, dim3(batch), dim3(256), 0, st, n, npad, d_AB, d_d, d_e, dbuf);
+            BSP_HIP(hipStreamSynchronize(st));
+            BSP_HIP(hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost));
+            hipFree(dbuf);
+            static const char *nm[12] = {"P5->P1 gap", "issue loads", "P1 compute", "barrier1", "P2 (wave0 house)", "barrier2",
+                                         "P3 compute", "barrier3", "P4 finalize", "barrier4", "P5 update+store", "sweep start"};
+            for (int wv = 0; wv < 4; ++wv) {
+                long long tot = 0;
+                for (int q = 0; q < 12; ++q) tot += h[wv * 12 + q];
+                fprintf(stderr, "sb2st diag wave %d (cycles, share):", wv);
+                for (int q = 0; q < 12; ++q) fprintf(stderr, " [%s %lld %.1f%%]", nm[q], h[wv * 12 + q], 100.0 * h[wv * 12 + q] / (double)tot);
+                fprintf(stderr, "\n");
+            }
+        }
+    }
     else {
         static int dbg = -1;
         if (dbg < 0) { const char *e = getenv("BSP_SB2ST_DBG"); dbg = e ? atoi(e) : 0; }

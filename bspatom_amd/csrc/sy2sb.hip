@@ -263,7 +263,7 @@ __global__ void extract_band_kernel(int npad, const double *__restrict__ Aall, d
     // AB[d + j*2NB] = A(j+d, j), d = 0..NB ; zero for d > NB or j+d >= npad
     const size_t ch = blockIdx.y;
     const double *A = Aall + ch * (size_t)npad * npad;
-    double *AB = ABall + ch * (size_t)npad * 2 * NB;
+    double *AB = ABall + ch * ab_stride(npad);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npad * 2 * NB) return;
     const int d = idx % (2 * NB), j = idx / (2 * NB);
