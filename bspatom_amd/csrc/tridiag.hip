@@ -25,6 +25,13 @@ __device__ __forceinline__ int sturm_count(const double *__restrict__ d, const d
     return cnt;
 }
 
+// EPT eigenvalues per thread: EPT independent Sturm recurrences share every LDS read of (d_i, e_i^2)
+// and hide each other's latency (the recurrence is one long dependent chain per shift).
+// The quotient e^2/q uses v_rcp_f64 refined by one Newton step (error a few ulp): only the SIGN of
+// each pivot enters the count, and a relative perturbation of e_i^2 of a few ulp moves every
+// eigenvalue by at most a few ulp of |T| -- the same bound plain bisection has.
+constexpr int EPT = 4;
+
 __global__ __launch_bounds__(256) void bisect_kernel(int n, int ldn, const double *__restrict__ dall,
                                                     const double *__restrict__ eall, double *wall, long ldw)
 {
@@ -45,7 +52,6 @@ __global__ __launch_bounds__(256) void bisect_kernel(int n, int ldn, const doubl
         gu = fmax(gu, di + el + er);
         emax = fmax(emax, er * er);
     }
-    // workgroup min/max
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         gl = fmin(gl, __shfl_xor(gl, off));
@@ -67,21 +73,56 @@ __global__ __launch_bounds__(256) void bisect_kernel(int n, int ldn, const doubl
     gl = gl - 2.1 * tnorm * eps * n - 2.1 * pivmin;
     gu = gu + 2.1 * tnorm * eps * n + 2.1 * pivmin;
 
-    const int m = blockIdx.x * 256 + tid;      // eigenvalue index
-    const bool act = m < n;
-    double lo = gl, hi = gu;
-    // every thread runs the same number of steps (LDS broadcast reads stay uniform); a thread
-    // whose bracket has converged keeps evaluating its midpoint harmlessly.
+    const int mbase = blockIdx.x * (256 * EPT) + tid;      // eigenvalue indices mbase + 256 c
+    double lo[EPT], hi[EPT];
+#pragma unroll
+    for (int c = 0; c < EPT; ++c) { lo[c] = gl; hi[c] = gu; }
     for (int it = 0; it < 128; ++it) {
-        const double mid = 0.5 * (lo + hi);
-        const bool done = (mid <= lo) || (mid >= hi) || (hi - lo <= 2.0 * eps * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin);
-        if (__syncthreads_and(done)) break;
-        const int c = sturm_count(d, e2, n, mid, pivmin);
-        if (!done) {
-            if (c > m) hi = mid; else lo = mid;
+        double mid[EPT];
+        bool done[EPT];
+        bool alld = true;
+#pragma unroll
+        for (int c = 0; c < EPT; ++c) {
+            mid[c] = 0.5 * (lo[c] + hi[c]);
+            done[c] = (mid[c] <= lo[c]) || (mid[c] >= hi[c]) ||
+                      (hi[c] - lo[c] <= 2.0 * eps * fmax(fabs(lo[c]), fabs(hi[c])) + 2.0 * pivmin);
+            alld = alld && done[c];
+        }
+        if (__syncthreads_and(alld)) break;
+        double q[EPT];
+        int cnt[EPT];
+        {
+            const double d0 = d[0];
+#pragma unroll
+            for (int c = 0; c < EPT; ++c) {
+                q[c] = d0 - mid[c];
+                if (fabs(q[c]) < pivmin) q[c] = -pivmin;
+                cnt[c] = (q[c] < 0.0) ? 1 : 0;
+            }
+        }
+        for (int i = 1; i < n; ++i) {
+            const double di = d[i], ei = e2[i - 1];
+#pragma unroll
+            for (int c = 0; c < EPT; ++c) {
+                double r = __builtin_amdgcn_rcp(q[c]);
+                r = r * (2.0 - q[c] * r);                   // one Newton step
+                q[c] = (di - mid[c]) - ei * r;
+                if (fabs(q[c]) < pivmin) q[c] = -pivmin;
+                cnt[c] += (q[c] < 0.0) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < EPT; ++c) {
+            if (!done[c]) {
+                if (cnt[c] > mbase + 256 * c) hi[c] = mid[c]; else lo[c] = mid[c];
+            }
         }
     }
-    if (act) wall[ch * (size_t)ldw + m] = 0.5 * (lo + hi);
+#pragma unroll
+    for (int c = 0; c < EPT; ++c) {
+        const int m = mbase + 256 * c;
+        if (m < n) wall[ch * (size_t)ldw + m] = 0.5 * (lo[c] + hi[c]);
+    }
 }
 
 int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_e, double *d_w, long ldw,
@@ -95,7 +136,7 @@ int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(bisect_kernel, dim3((n + 255) / 256, batch), dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
+    hipLaunchKernelGGL(bisect_kernel, dim3((n + 256 * EPT - 1) / (256 * EPT), batch), dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }
