@@ -70,6 +70,24 @@ def cpu_baseline(sample_nfun, k):
             "value_scaled_to_nfun4096": (1.0 / t) * (sample_nfun / 4096.0) ** 3}
 
 
+def pmc_traffic(kernel, channels, nfun):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 cannot run
+    inside this process): profiles/*_pmc_summary.json written by tools/pmc_summary.py from two separate
+    --pmc passes (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE exact).  None if no summary matches."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload", {}).get("channels") != channels or d.get("workload", {}).get("nfun") != nfun:
+            continue
+        for k, v in d.get("kernels", {}).items():
+            if kernel.split()[0].split("_kernel")[0] in k:
+                return v["traffic_bytes_per_launch"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,7 +185,8 @@ def main():
             roof = {"kernel": names[dom], "bound": "hbm", "achieved": alg / (stage_ms[dom] * 1e-3) / 1e9,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["traffic"] = None
+        roof["algorithmic"] = alg                     # bytes (hbm) or flop (mfma) per launch
+        roof["traffic"] = pmc_traffic(roof["kernel"], nl, n)
         roof["launch_ms"] = float(stage_ms[dom])
         out = {
             "metric": "l-channel eigensolves/sec at N_bsp=%d fp64" % n, "value": value, "unit": "eigensolves/s",

@@ -236,7 +236,7 @@ __device__ __forceinline__ void tile_store(const double2 (&r)[BK * BX / 512], do
 
 // kernel view: C'(i', j') with j' memory-contiguous (sCn == 1 required).
 template <int BM, int BN, int ALAY, int BLAY, int MODE>
-__global__ __launch_bounds__(256) void gemm2_kernel(GemmDesc g)
+__global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmDesc g)
 {
     constexpr int WM = 2, WN = 2;
     constexpr int LDA = BM + 16, LDB = BN + 16;

@@ -755,12 +755,272 @@ __global__ __launch_bounds__(256) void sb2st_kernel_v3(int n, int npad, double *
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// v4: TWO SWEEPS IN FLIGHT per workgroup.  512 threads = two halves of 4 wavefronts; half h works on
+// sweeps s = h, h+2, h+4, ... with the v3 step (register tiles, 4 phases), both halves on the SAME
+// barriers, so the serial reflector phases and the load/store issue of one half overlap with the
+// other half on the CU's four SIMDs.  Sweep s+1 may touch an item only when sweep s is LAG items
+// past it (region overlap is 1 item, its prefetch 1 more, store completion 3 more).
+// Everything inside a super-step is branch-free and mask-driven (no control flow around loads):
+//   PRELOAD : nothing computed; the "prefetch" fetches the sweep's first diagonal block (B masked to 0)
+//   ITEM0   : the sweep start = a chase item with an empty B tile whose reflector comes from column s
+//   CHASE   : as v3
+//   IDLE    : all masks off (waiting for the other half, or finished)
+constexpr int SB4_LAG = 6;
+enum { ACT_IDLE = 0, ACT_PRELOAD = 1, ACT_ITEM0 = 2, ACT_CHASE = 3 };
+
+struct Sb4Shared {
+    Sb3Lds S[2];
+    int sweep[2], done[2], fin[2], viol;
+};
+
+template <int PAR>
+__device__ __forceinline__ void superstep_v4(double *__restrict__ AB, Sb4Shared &SH, int h, int htid, int ib, int j0,
+                                             const unsigned (&off)[4][4], unsigned low, int n,
+                                             int &state, int &sw, ChaseState &st, double &xpre,
+                                             double (&Bc)[4][4], double (&Dc)[4][4], double (&Bn)[4][4], double (&Dn)[4][4])
+{
+    constexpr int LD = 2 * SB;
+    Sb3Lds &S = SH.S[h];
+    const double *vc = PAR ? S.vb : S.va;
+    double *vn = PAR ? S.va : S.vb;
+    const int jb = j0 >> 2;
+    lds_barrier();                                           // barrier 0: progress of both halves is published
+    // ---- decide (identical in every thread of the half) ----
+    int act = ACT_IDLE;
+    {
+        const int o = h ^ 1;
+        const int osw = SH.sweep[o], odn = SH.done[o], ofin = SH.fin[o];
+        if (state == 1) {                                    // NEED_PRELOAD: may item 0 of sweep sw start?
+            const bool ok = (sw == 0) || ofin || (osw > sw - 1) || (osw == sw - 1 && odn >= SB4_LAG);
+            act = ok ? ACT_PRELOAD : ACT_IDLE;
+        } else if (state == 2) act = ACT_ITEM0;
+        else if (state == 3) act = ACT_CHASE;
+        if (act >= ACT_ITEM0 && sw > 0 && !ofin && !(osw > sw - 1)) {
+            const int k = (act == ACT_ITEM0) ? 0 : SH.done[h];
+            if (!(osw == sw - 1 && odn >= k + SB4_LAG - 1) && htid == 0) atomicAdd(&SH.viol, 1);   // must not happen
+        }
+    }
+    const bool all_fin = SH.fin[0] && SH.fin[1];
+    if (all_fin) { state = -1; return; }
+    const bool comp = (act >= ACT_ITEM0);
+    const bool item0 = (act == ACT_ITEM0);
+    const int L0 = (n - 1 - sw < SB) ? (n - 1 - sw) : SB;   // first block size of sweep sw
+    if (item0) { st.r0 = sw + 1; st.L = 0; st.L2 = L0; st.tau = 0.0; }
+    const int r0 = comp ? st.r0 : 0, L = comp ? st.L : 0, L2 = comp ? st.L2 : 0, rn = r0 + L;
+    // what to prefetch: PRELOAD -> tiles of item 0 (B empty, D2 at sw+1); ITEM0/CHASE -> the next chase item
+    int pr0, pL, pL2;
+    bool have_pf;
+    if (act == ACT_PRELOAD) { pr0 = sw + 1; pL = 0; pL2 = L0; have_pf = true; }
+    else {
+        have_pf = comp && (rn + L2 < n);
+        pr0 = rn; pL = L2; pL2 = have_pf ? ((n - (rn + L2) < SB) ? (n - (rn + L2)) : SB) : 0;
+    }
+    // ---- P1 ----
+    {
+        const double *__restrict__ Bb = have_pf ? (AB + ((size_t)pr0 * LD + pL)) : AB;
+        const double *__restrict__ Db = have_pf ? (AB + (size_t)(pr0 + pL) * LD) : AB;
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const int i = SB3_ROW(ri), j = SB3_COL(cj);
+                const bool okb = have_pf && (i < pL2) && (j < pL);
+                const bool okd = have_pf && ((low >> (ri * 4 + cj)) & 1u) && (i < pL2);
+                const double bv = Bb[okb ? off[ri][cj] : 0u];
+                const double dv = Db[okd ? off[ri][cj] : 0u];
+                Bn[ri][cj] = okb ? bv : 0.0;
+                Dn[ri][cj] = okd ? dv : 0.0;
+            }
+        // column sw of the band (the sweep's first reflector), fetched by wave 0 of the half during PRELOAD
+        if (htid < 64) {
+            const bool okx = (act == ACT_PRELOAD) && (htid < L0);
+            const double xr = AB[okx ? ((size_t)sw * LD + 1 + htid) : 0];
+            xpre = (act == ACT_PRELOAD) ? (okx ? xr : 0.0) : xpre;
+        }
+        double vcj[4];
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) vcj[cj] = vc[j0 + cj];
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            double a = 0.0;
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj) a += Bc[ri][cj] * vcj[cj];
+            S.R1[jb][SB3_ROW(ri)] = a;
+        }
+        if (jb == 0) {
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) S.x0[SB3_ROW(ri)] = Bc[ri][0];
+        }
+    }
+    lds_barrier();
+    // ---- P2: wave 0 of the half ----
+    if (htid < 64) {
+        const int i = htid;
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += S.R1[q][i];
+        const double wi = item0 ? 0.0 : st.tau * a;
+        const double xc = item0 ? xpre : (S.x0[i] - wi * vc[0]);
+        const double xi = (i < L2) ? xc : 0.0;
+        double beta2, tau2;
+        const double vi = wave_house(xi, i, L2, &beta2, &tau2);
+        const double sdot = wave_sum(vi * wi);
+        S.w[i] = wi; vn[i] = vi;
+        if (i == 0) { S.sc[1] = beta2; S.sc[2] = tau2; S.sc[3] = sdot; }
+    }
+    lds_barrier();
+    const double beta2 = S.sc[1], tau2 = S.sc[2], sdot = S.sc[3];
+    // ---- P3 ----
+    double vni[4], vnj[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { vni[x] = vn[SB3_ROW(x)]; vnj[x] = vn[j0 + x]; }
+    {
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+            double a = 0.0;
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) a += vni[ri] * Bc[ri][cj];
+            S.R2[ib][j0 + cj] = a;
+        }
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            double a = 0.0;
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj) a += Dc[ri][cj] * vnj[cj];
+            S.R3[jb][SB3_ROW(ri)] = a;
+        }
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+            double a = 0.0;
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) a += (SB3_ROW(ri) != j0 + cj) ? Dc[ri][cj] * vni[ri] : 0.0;
+            S.R4[ib][j0 + cj] = a;
+        }
+    }
+    lds_barrier();
+    // ---- P4 ----
+    if (htid < 64) {
+        const int j = htid;
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += S.R2[q][j];
+        S.z[j] = tau2 * (a - sdot * vc[j]);
+    } else if (htid < 128) {
+        const int i = htid - 64;
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += S.R3[q][i] + S.R4[q][i];
+        const double pi = tau2 * a;
+        const double dot = wave_sum(pi * vn[i]);
+        S.pv[i] = pi + (-0.5 * tau2 * dot) * vn[i];
+    }
+    lds_barrier();
+    // ---- P5 ----
+    {
+        double wi[4], zj[4], vcj[4], pi[4], pj[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            wi[x] = S.w[SB3_ROW(x)]; zj[x] = S.z[j0 + x]; vcj[x] = vc[j0 + x]; pi[x] = S.pv[SB3_ROW(x)]; pj[x] = S.pv[j0 + x];
+        }
+        double *__restrict__ Bb = AB + ((size_t)r0 * LD + L);
+        double *__restrict__ Db = AB + (size_t)rn * LD;
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const int i = SB3_ROW(ri), j = j0 + cj;
+                double bnew = Bc[ri][cj] - (wi[ri] * vcj[cj] + vni[ri] * zj[cj]);
+                if (j == 0) bnew = (i == 0) ? beta2 : 0.0;
+                if (i < L2 && j < L) Bb[off[ri][cj]] = bnew;
+                if (((low >> (ri * 4 + cj)) & 1u) && i < L2)
+                    Db[off[ri][cj]] = Dc[ri][cj] - (vni[ri] * pj[cj] + pi[ri] * vnj[cj]);
+            }
+        if (item0 && htid < L2) AB[(size_t)sw * LD + 1 + htid] = (htid == 0) ? beta2 : 0.0;
+    }
+    // ---- state update + publication (read by the other half after the next barrier 0) ----
+    if (act == ACT_PRELOAD) state = 2;
+    else if (comp) {
+        const bool more = (rn + L2 < n);
+        st.r0 = rn; st.L = L2; st.L2 = pL2; st.tau = tau2;
+        int dn = (act == ACT_ITEM0) ? 1 : (SH.done[h] + 1);
+        if (more) state = 3;
+        else {                                               // sweep finished
+            sw += 2; dn = 0;
+            const int Lnext = (n - 1 - sw < SB) ? (n - 1 - sw) : SB;
+            state = (sw < n - 2 && Lnext >= 2) ? 1 : 0;
+        }
+        if (htid == 0) { SH.sweep[h] = sw; SH.done[h] = dn; if (state == 0) SH.fin[h] = 1; }
+    }
+}
+
+__global__ __launch_bounds__(512) void sb2st_kernel_v4(int n, int npad, double *ABall, double *dall, double *eall,
+                                                      int *viol_out)
+{
+    __shared__ Sb4Shared SH;
+    constexpr int LD = 2 * SB;
+    const int tid = threadIdx.x, h = tid >> 8, htid = tid & 255, lane = tid & 63, hwave = htid >> 6;
+    const int ib = lane & 15, jb = (lane >> 4) + 4 * hwave;
+    const int j0 = 4 * jb;
+    unsigned off[4][4], low = 0;
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            const int i = SB3_ROW(ri), j = j0 + cj;
+            off[ri][cj] = (unsigned)(j * (LD - 1) + i);
+            if (i >= j) low |= 1u << (ri * 4 + cj);
+        }
+    const size_t ch = blockIdx.x;
+    double *AB = ABall + ch * ab_stride(npad);
+    if (tid == 0) { SH.viol = 0; }
+    if (htid == 0) {
+        const int L0 = (n - 1 - h < SB) ? (n - 1 - h) : SB;
+        const bool any = (h < n - 2) && (L0 >= 2);
+        SH.sweep[h] = h; SH.done[h] = 0; SH.fin[h] = any ? 0 : 1;
+    }
+    __syncthreads();
+    int state = SH.fin[h] ? 0 : 1, sw = h;
+    ChaseState st; st.r0 = 0; st.L = 0; st.L2 = 0; st.L3 = 0; st.tau = 0.0;
+    double xpre = 0.0;
+    double B0[4][4], D0[4][4], B1[4][4], D1[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { B0[a][c] = 0.0; D0[a][c] = 0.0; B1[a][c] = 0.0; D1[a][c] = 0.0; }
+    for (;;) {
+        superstep_v4<0>(AB, SH, h, htid, ib, j0, off, low, n, state, sw, st, xpre, B0, D0, B1, D1);
+        if (state < 0) break;
+        superstep_v4<1>(AB, SH, h, htid, ib, j0, off, low, n, state, sw, st, xpre, B1, D1, B0, D0);
+        if (state < 0) break;
+    }
+    __syncthreads();
+    if (tid == 0 && SH.viol) atomicAdd(viol_out, SH.viol);
+    double *d = dall + ch * (size_t)npad, *e = eall + ch * (size_t)npad;
+    for (int j = tid; j < n; j += 512) {
+        d[j] = AB[(size_t)j * LD];
+        e[j] = (j < n - 1) ? AB[(size_t)j * LD + 1] : 0.0;
+    }
+}
+
 int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st)
 {
     if (b != SB) return BSP_ERR_ARG;
     static int ver = -1;
     if (ver < 0) { const char *e = getenv("BSP_SB2ST_VERSION"); ver = e ? atoi(e) : 3; }
     if (ver == 1) hipLaunchKernelGGL(sb2st_kernel, dim3(batch), dim3(256), 0, st, n, npad, d_AB, d_d, d_e);
+    else if (ver == 4) {
+        static int *d_viol = nullptr;
+        if (!d_viol) { BSP_HIP(hipMalloc(reinterpret_cast<void **>(&d_viol), sizeof(int))); BSP_HIP(hipMemset(d_viol, 0, sizeof(int))); }
+        hipLaunchKernelGGL(sb2st_kernel_v4, dim3(batch), dim3(512), 0, st, n, npad, d_AB, d_d, d_e, d_viol);
+        if (getenv("BSP_SB2ST_CHECK")) {
+            int hv = 0;
+            BSP_HIP(hipStreamSynchronize(st));
+            BSP_HIP(hipMemcpy(&hv, d_viol, sizeof(int), hipMemcpyDeviceToHost));
+            if (hv) { fprintf(stderr, "bspatom: sb2st v4 dependency violations: %d\n", hv); return BSP_ERR_HIP; }
+        }
+    }
     else if (ver == 3) {
         static int diag = -1;
         if (diag < 0) { const char *e = getenv("BSP_SB2ST_DIAG"); diag = e ? atoi(e) : 0; }
