@@ -115,7 +115,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libbspatom has no CPU path")
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
 
@@ -126,7 +127,7 @@ def main():
     prob = capi.Problem(inp, device=local)
     n = prob.nfun
     E_dev = torch.empty(nl * n, dtype=torch.float64, device="cuda")
-    E_all = torch.empty(world * nl * n, dtype=torch.float64, device="cuda") if world > 1 else E_dev
+    E_all = torch.empty(world * nl * n, dtype=torch.float64, device="cuda") if use_dist else E_dev
 
     stage_ms = np.zeros(6)
 
@@ -139,11 +140,11 @@ def main():
         if rank == 0:                 # owner of l_ini = 0: the one eigenvector KIND_PI=0 consumes + WRITE_WF
             c = prob.eigvec(0, 1)
             prob.write_wf(c)
-        if world > 1:
-            dist.all_gather_into_tensor(E_all, E_dev)
+        if use_dist:
+            dist.all_gather_into_tensor(E_all, E_dev)      # RCCL: the only collective of the path
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -155,7 +156,7 @@ def main():
         step(True)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -203,7 +204,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_nfun, args.k)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     prob.close()
