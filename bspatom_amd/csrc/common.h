@@ -42,11 +42,13 @@ struct GemmDesc {
     double *C; long sCm, sCn, bC;
     double alpha, beta;
     int lower_only;   // 1: C is square/symmetric, compute only tiles touching i >= j (col-major C)
+    int yoff;         // gemm2 MODE 1: first kernel-view row block (= caller column block) of this launch
 };
 int gemm_f64(const GemmDesc &g, hipStream_t st);
 // pipelined, symmetry-aware products of sy2sb (see gemm_f64.hip)
+// part: 0 = all tiles, 1 = only column block 0 (look-ahead part), 2 = column blocks >= 1
 int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const double *buf, long ldb, long bsBuf,
-                    hipStream_t st);
+                    int part, hipStream_t st);
 int symm_lower_f64(int m, int batch, const double *A22, long ld, long bsA, const double *W, long ldw, long bsW,
                    double *Y, long ldy, long bsY, hipStream_t st);
 
@@ -65,6 +67,8 @@ int launch_standard_form(int n, int npad, int k, int nl, const double *d_HB, con
                          const double *d_rdiag, double *d_Y, double *d_C, hipStream_t st);
 // sy2sb.hip
 struct Sy2sbWork {
+    double *buf2;   // second [V | Z | V] set (panels alternate: look-ahead QR writes one while the update reads the other)
+    double *tau2;
     double *buf;    // [batch][npad][3*nb]  : [V | Z | V]
     double *W;      // [batch][npad][nb]
     double *G;      // [batch][nb][nb]

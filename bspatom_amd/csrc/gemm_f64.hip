@@ -245,8 +245,9 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmDesc g)
     __shared__ double Bs[2][BK * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    if (MODE == 1 && (int)blockIdx.y > (int)blockIdx.x + 1) return;     // column block > row block + 1
+    const int by = blockIdx.y + (MODE == 1 ? g.yoff : 0);
+    const int m0 = by * BM, n0 = blockIdx.x * BN;
+    if (MODE == 1 && by > (int)blockIdx.x + 1) return;                  // column block > row block + 1
     const double *A = g.A + (long)blockIdx.z * g.bA;
     const double *B = g.B + (long)blockIdx.z * g.bB;
     double *C = g.C + (long)blockIdx.z * g.bC;
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmDesc g)
 // A22 (m x m, column-major, ld) -= P Q^T with P = buf[:, 0:128], Q = buf[:, 64:192] (ldb rows apart),
 // only tiles with column block <= row block + 1.
 int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const double *buf, long ldb, long bsBuf,
-                    hipStream_t st)
+                    int part, hipStream_t st)
 {
     GemmDesc g{};
     g.M = m; g.N = m; g.K = 128; g.batch = batch;
@@ -341,7 +342,13 @@ int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const doub
     g.B = buf; g.sBn = 1; g.sBk = ldb; g.bB = bsBuf;                  // kernel-B(k, j'=r) = P(r, k)
     g.C = A22; g.sCm = ld; g.sCn = 1; g.bC = bsA;                     // C'(c, r) = A22(r, c)
     g.alpha = -1.0; g.beta = 1.0; g.lower_only = 0;
-    dim3 grid((m + 127) / 128, (m + 127) / 128, batch);
+    const int nb = (m + 127) / 128;
+    int ny = nb;
+    g.yoff = 0;
+    if (part == 1) ny = 1;
+    else if (part == 2) { g.yoff = 1; ny = nb - 1; }
+    if (ny <= 0) return BSP_OK;
+    dim3 grid(nb, ny, batch);
     hipLaunchKernelGGL((gemm2_kernel<128, 128, 0, 0, 1>), grid, dim3(256), 0, st, g);
     BSP_HIP(hipGetLastError());
     return BSP_OK;

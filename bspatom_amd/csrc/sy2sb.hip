@@ -275,7 +275,7 @@ __global__ void extract_band_kernel(int npad, const double *__restrict__ Aall, d
 size_t sy2sb_work_bytes(int npad, int nb, int batch)
 {
     (void)nb;
-    size_t per = (size_t)npad * 3 * NB + (size_t)npad * NB + 3 * NB * NB + NB;
+    size_t per = 2 * ((size_t)npad * 3 * NB + NB) + (size_t)npad * NB + 3 * NB * NB;
     return per * batch * sizeof(double);
 }
 
@@ -284,11 +284,13 @@ void sy2sb_carve(void *base, int npad, int nb, int batch, Sy2sbWork *w)
     (void)nb;
     double *p = static_cast<double *>(base);
     w->buf = p; p += (size_t)batch * npad * 3 * NB;
+    w->buf2 = p; p += (size_t)batch * npad * 3 * NB;
     w->W = p; p += (size_t)batch * npad * NB;
     w->G = p; p += (size_t)batch * NB * NB;
     w->T = p; p += (size_t)batch * NB * NB;
     w->Kmat = p; p += (size_t)batch * NB * NB;
-    w->tau = p;
+    w->tau = p; p += (size_t)batch * NB;
+    w->tau2 = p;
 }
 
 template <int RPT>
@@ -297,72 +299,97 @@ static void launch_pq(int npad, int r0, int c0, int batch, double *A, double *bu
     hipLaunchKernelGGL((panel_qr_kernel<RPT>), dim3(batch), dim3(PQ_THREADS), 0, st, npad, r0, c0, A, buf, tau);
 }
 
+// Panel factorisation + T + W = V T for the panel whose columns start at c0 (enqueued on `s`).
+static int panel_and_W(int npad, int c0, int batch, double *d_A, double *buf, double *tau, const Sy2sbWork &w,
+                       hipStream_t s)
+{
+    const int r0 = c0 + NB, m = npad - r0;
+    const long bsBuf = (long)npad * 3 * NB, bsW = (long)npad * NB, bsS = NB * NB;
+    const int rpt = (m + PQ_THREADS - 1) / PQ_THREADS;
+    if (rpt <= 1) launch_pq<1>(npad, r0, c0, batch, d_A, buf, tau, s);
+    else if (rpt <= 2) launch_pq<2>(npad, r0, c0, batch, d_A, buf, tau, s);
+    else if (rpt <= 4) launch_pq<4>(npad, r0, c0, batch, d_A, buf, tau, s);
+    else if (rpt <= 8) launch_pq<8>(npad, r0, c0, batch, d_A, buf, tau, s);
+    else launch_pq<16>(npad, r0, c0, batch, d_A, buf, tau, s);
+    BSP_HIP(hipGetLastError());
+    int rc;
+    GemmDesc g{};
+    g.batch = batch;
+    // G = V^T V
+    g.M = NB; g.N = NB; g.K = m;
+    g.A = buf; g.sAm = npad; g.sAk = 1; g.bA = bsBuf;
+    g.B = buf; g.sBk = 1; g.sBn = npad; g.bB = bsBuf;
+    g.C = w.G; g.sCm = NB; g.sCn = 1; g.bC = bsS; g.alpha = 1.0; g.beta = 0.0;
+    if ((rc = gemm_f64(g, s))) return rc;
+    hipLaunchKernelGGL(form_T_kernel, dim3(batch), dim3(64), 0, s, w.G, tau, w.T);
+    BSP_HIP(hipGetLastError());
+    // W = V T
+    g.M = m; g.N = NB; g.K = NB;
+    g.A = buf; g.sAm = 1; g.sAk = npad; g.bA = bsBuf;
+    g.B = w.T; g.sBk = 1; g.sBn = NB; g.bB = bsS;
+    g.C = w.W; g.sCm = 1; g.sCn = npad; g.bC = bsW; g.alpha = 1.0; g.beta = 0.0;
+    return gemm_f64(g, s);
+}
+
+// Look-ahead schedule: after the block column that holds the next panel has been updated (syr2k
+// part 1), QR(p+1), T and W(p+1) run on a side stream while the rest of the HBM-bound update
+// (part 2) proceeds on the main stream; the two [V|Z|V] buffers alternate between panels.
 int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipStream_t st)
 {
     if (nb != NB || npad % NB != 0) return BSP_ERR_ARG;
     if (npad - NB > PQ_THREADS * 16) return BSP_ERR_UNSUPPORTED;   // n <= 8256
-    static int g_sym = -1;      // BSP_SY2SB_SYM=0 selects the plain full-storage GEMMs (A/B testing)
-    if (g_sym < 0) { const char *e = getenv("BSP_SY2SB_SYM"); g_sym = e ? atoi(e) : 1; }
+    static hipStream_t side = nullptr;
+    static hipEvent_t evA = nullptr, evB = nullptr;
+    static int lookahead = -1;
+    if (lookahead < 0) { const char *e = getenv("BSP_SY2SB_LOOKAHEAD"); lookahead = e ? atoi(e) : 1; }
+    if (!side) {
+        int plo = 0, phi = 0;                      // the latency-bound panel work gets the high-priority queue
+        BSP_HIP(hipDeviceGetStreamPriorityRange(&plo, &phi));
+        BSP_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, phi));
+        BSP_HIP(hipEventCreateWithFlags(&evA, hipEventDisableTiming));
+        BSP_HIP(hipEventCreateWithFlags(&evB, hipEventDisableTiming));
+    }
     const long ld = npad;
     const long bsA = (long)npad * npad, bsBuf = (long)npad * 3 * NB, bsW = (long)npad * NB, bsS = NB * NB;
-    for (int c0 = 0; c0 + NB < npad; c0 += NB) {
-        const int r0 = c0 + NB, m = npad - r0;
-        const int rpt = (m + PQ_THREADS - 1) / PQ_THREADS;
-        if (rpt <= 1) launch_pq<1>(npad, r0, c0, batch, d_A, w.buf, w.tau, st);
-        else if (rpt <= 2) launch_pq<2>(npad, r0, c0, batch, d_A, w.buf, w.tau, st);
-        else if (rpt <= 4) launch_pq<4>(npad, r0, c0, batch, d_A, w.buf, w.tau, st);
-        else if (rpt <= 8) launch_pq<8>(npad, r0, c0, batch, d_A, w.buf, w.tau, st);
-        else launch_pq<16>(npad, r0, c0, batch, d_A, w.buf, w.tau, st);
-        BSP_HIP(hipGetLastError());
-        int rc;
-        GemmDesc g{};
-        g.batch = batch; g.lower_only = 0;
-        // G = V^T V
-        g.M = NB; g.N = NB; g.K = m;
-        g.A = w.buf; g.sAm = npad; g.sAk = 1; g.bA = bsBuf;
-        g.B = w.buf; g.sBk = 1; g.sBn = npad; g.bB = bsBuf;
-        g.C = w.G; g.sCm = NB; g.sCn = 1; g.bC = bsS; g.alpha = 1.0; g.beta = 0.0;
-        if ((rc = gemm_f64(g, st))) return rc;
-        hipLaunchKernelGGL(form_T_kernel, dim3(batch), dim3(64), 0, st, w.G, w.tau, w.T);
-        BSP_HIP(hipGetLastError());
-        // W = V T
-        g.M = m; g.N = NB; g.K = NB;
-        g.A = w.buf; g.sAm = 1; g.sAk = npad; g.bA = bsBuf;
-        g.B = w.T; g.sBk = 1; g.sBn = NB; g.bB = bsS;
-        g.C = w.W; g.sCm = 1; g.sCn = npad; g.bC = bsW; g.alpha = 1.0; g.beta = 0.0;
-        if ((rc = gemm_f64(g, st))) return rc;
-        // Y = A22 W  -> buf[:, NB:2NB]   (A22 valid on 64-blocks J <= I+1 only)
+    const int P = npad / NB - 1;
+    int rc;
+    if (P <= 0) return BSP_OK;
+    if ((rc = panel_and_W(npad, 0, batch, d_A, w.buf, w.tau, w, st))) return rc;
+    for (int p = 0; p < P; ++p) {
+        const int c0 = p * NB, r0 = c0 + NB, m = npad - r0;
+        double *buf = (p & 1) ? w.buf2 : w.buf;
+        double *bufn = (p & 1) ? w.buf : w.buf2;
+        double *taun = (p & 1) ? w.tau : w.tau2;
         double *A22 = d_A + (size_t)r0 * ld + r0;
-        if (g_sym) {
-            if ((rc = symm_lower_f64(m, batch, A22, ld, bsA, w.W, npad, bsW, w.buf + (size_t)NB * npad, npad, bsBuf, st))) return rc;
-        } else {
-            g.M = m; g.N = NB; g.K = m;
-            g.A = A22; g.sAm = 1; g.sAk = ld; g.bA = bsA;
-            g.B = w.W; g.sBk = 1; g.sBn = npad; g.bB = bsW;
-            g.C = w.buf + (size_t)NB * npad; g.sCm = 1; g.sCn = npad; g.bC = bsBuf; g.alpha = 1.0; g.beta = 0.0;
-            if ((rc = gemm_f64(g, st))) return rc;
-        }
+        GemmDesc g{};
+        g.batch = batch;
+        // Y = A22 W  -> buf[:, NB:2NB]   (A22 valid on 64-blocks J <= I+1 only)
+        if ((rc = symm_lower_f64(m, batch, A22, ld, bsA, w.W, npad, bsW, buf + (size_t)NB * npad, npad, bsBuf, st))) return rc;
         // K = W^T Y
         g.M = NB; g.N = NB; g.K = m;
         g.A = w.W; g.sAm = npad; g.sAk = 1; g.bA = bsW;
-        g.B = w.buf + (size_t)NB * npad; g.sBk = 1; g.sBn = npad; g.bB = bsBuf;
+        g.B = buf + (size_t)NB * npad; g.sBk = 1; g.sBn = npad; g.bB = bsBuf;
         g.C = w.Kmat; g.sCm = 1; g.sCn = NB; g.bC = bsS; g.alpha = 1.0; g.beta = 0.0;
         if ((rc = gemm_f64(g, st))) return rc;
         // Z = Y - 1/2 V K  (in place)
         g.M = m; g.N = NB; g.K = NB;
-        g.A = w.buf; g.sAm = 1; g.sAk = npad; g.bA = bsBuf;
+        g.A = buf; g.sAm = 1; g.sAk = npad; g.bA = bsBuf;
         g.B = w.Kmat; g.sBk = 1; g.sBn = NB; g.bB = bsS;
-        g.C = w.buf + (size_t)NB * npad; g.sCm = 1; g.sCn = npad; g.bC = bsBuf; g.alpha = -0.5; g.beta = 1.0;
+        g.C = buf + (size_t)NB * npad; g.sCm = 1; g.sCn = npad; g.bC = bsBuf; g.alpha = -0.5; g.beta = 1.0;
         if ((rc = gemm_f64(g, st))) return rc;
         // A22 -= [V Z] [Z V]^T
-        if (g_sym) {
-            if ((rc = syr2k_lower_f64(m, batch, A22, ld, bsA, w.buf, npad, bsBuf, st))) return rc;
+        const bool more = (p + 1 < P);
+        if (lookahead && more) {
+            if ((rc = syr2k_lower_f64(m, batch, A22, ld, bsA, buf, npad, bsBuf, 1, st))) return rc;
+            BSP_HIP(hipEventRecord(evA, st));
+            BSP_HIP(hipStreamWaitEvent(side, evA, 0));
+            if ((rc = panel_and_W(npad, r0, batch, d_A, bufn, taun, w, side))) return rc;
+            BSP_HIP(hipEventRecord(evB, side));
+            if ((rc = syr2k_lower_f64(m, batch, A22, ld, bsA, buf, npad, bsBuf, 2, st))) return rc;
+            BSP_HIP(hipStreamWaitEvent(st, evB, 0));
         } else {
-            g.M = m; g.N = m; g.K = 2 * NB;
-            g.A = w.buf; g.sAm = 1; g.sAk = npad; g.bA = bsBuf;
-            g.B = w.buf + (size_t)NB * npad; g.sBk = npad; g.sBn = 1; g.bB = bsBuf;
-            g.C = A22; g.sCm = 1; g.sCn = ld; g.bC = bsA; g.alpha = -1.0; g.beta = 1.0;
-            if ((rc = gemm_f64(g, st))) return rc;
+            if ((rc = syr2k_lower_f64(m, batch, A22, ld, bsA, buf, npad, bsBuf, 0, st))) return rc;
+            if (more && (rc = panel_and_W(npad, r0, batch, d_A, bufn, taun, w, st))) return rc;
         }
     }
     return BSP_OK;
