@@ -222,7 +222,7 @@ int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const d
     if ((rc = sy2sb_run(npad, 64, nl, b.C, w, st))) return rc;
     if ((rc = launch_extract_band(npad, 64, nl, b.C, b.AB, st))) return rc;
     if (ev) BSP_HIP(hipEventRecord(ev[2], st));
-    if ((rc = launch_sb2st(n, npad, 64, nl, b.AB, b.d, b.e, st))) return rc;
+    if ((rc = launch_sb2st(n, npad, 64, nl, b.AB, b.d, b.e, st, b.status))) return rc;
     if (ev) BSP_HIP(hipEventRecord(ev[3], st));
     if ((rc = launch_bisect(n, npad, nl, b.d, b.e, d_Eout, n, st))) return rc;
     if (ev) BSP_HIP(hipEventRecord(ev[4], st));
@@ -242,7 +242,7 @@ static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, dou
     BSP_HIP(hipEventRecord(p->ev[0], p->st));
     if ((rc = enqueue_assemble(p, l0, nl))) return rc;
     BSP_HIP(hipEventRecord(p->ev[1], p->st));
-    PipeBufs pb{p->d_UB, p->d_rdiag, p->d_Y, p->d_C, p->d_AB, p->d_d, p->d_e, p->d_work, p->d_info};
+    PipeBufs pb{p->d_UB, p->d_rdiag, p->d_Y, p->d_C, p->d_AB, p->d_d, p->d_e, p->d_work, p->d_info, p->d_status};
     double *Eout = E_dev_out ? E_dev_out : p->d_E;
     if ((rc = pipeline_enqueue(n, np, h.k, nl, p->d_SB, p->d_HB, pb, Eout, p->st, &p->ev[1]))) return rc;
     if (E_dev_out)   // keep a copy for bspatom_eigvec

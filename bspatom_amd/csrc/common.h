@@ -82,7 +82,7 @@ int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipS
 int launch_extract_band(int npad, int nb, int batch, const double *d_A, double *d_AB, hipStream_t st);
 // sb2st.hip
 int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, double *d_e,
-                 hipStream_t st);
+                 hipStream_t st, int *d_status = nullptr);
 // tridiag.hip
 int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_e, double *d_w,
                   long ldw, hipStream_t st);
@@ -102,6 +102,7 @@ struct PipeBufs {
     double *UB, *rdiag, *Y, *C, *AB, *d, *e;
     void *work;
     int *info;
+    int *status = nullptr;   // device word set to a BSP_ERR_* code by kernels that detect a failure
 };
 size_t pipe_bytes_per_channel(int npad);
 int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const double *d_HB,
