@@ -22,7 +22,7 @@ struct bspatom_problem {
     int cap_nl = 0;
     double *d_SB = nullptr, *d_HB = nullptr, *d_UB = nullptr, *d_rdiag = nullptr;
     double *d_Y = nullptr, *d_C = nullptr, *d_AB = nullptr, *d_d = nullptr, *d_e = nullptr, *d_E = nullptr;
-    void *d_work = nullptr;
+    void *d_work = nullptr, *d_sbctl = nullptr;
     int *d_info = nullptr;
     // eigenvector / wave-function scratch
     double *d_vwork = nullptr, *d_vec = nullptr, *d_wfr = nullptr, *d_wfu = nullptr, *d_Esel = nullptr;
@@ -67,9 +67,9 @@ extern "C" int bspatom_host_setup(const bspatom_input *in, bspatom_sizes *s, dou
 static void free_solve_buffers(bspatom_problem *p)
 {
     hipFree(p->d_SB); hipFree(p->d_HB); hipFree(p->d_UB); hipFree(p->d_rdiag); hipFree(p->d_Y);
-    hipFree(p->d_C); hipFree(p->d_AB); hipFree(p->d_d); hipFree(p->d_e); hipFree(p->d_E); hipFree(p->d_work);
+    hipFree(p->d_C); hipFree(p->d_AB); hipFree(p->d_d); hipFree(p->d_e); hipFree(p->d_E); hipFree(p->d_work); hipFree(p->d_sbctl);
     p->d_SB = p->d_HB = p->d_UB = p->d_rdiag = p->d_Y = p->d_C = p->d_AB = p->d_d = p->d_e = p->d_E = nullptr;
-    p->d_work = nullptr;
+    p->d_work = nullptr; p->d_sbctl = nullptr;
     p->cap_nl = 0;
 }
 
@@ -168,6 +168,7 @@ static int ensure_capacity(bspatom_problem *p, int nl)
     BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_e), b * np * sizeof(double)));
     BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_E), b * n * sizeof(double)));
     BSP_HIP(hipMalloc(&p->d_work, sy2sb_work_bytes((int)np, 64, nl)));
+    BSP_HIP(hipMalloc(&p->d_sbctl, sb2st_ctl_bytes(nl)));
     if (!p->d_info) BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_info), sizeof(int)));
     p->cap_nl = nl;
     return BSP_OK;
@@ -222,7 +223,7 @@ int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const d
     if ((rc = sy2sb_run(npad, 64, nl, b.C, w, st))) return rc;
     if ((rc = launch_extract_band(npad, 64, nl, b.C, b.AB, st))) return rc;
     if (ev) BSP_HIP(hipEventRecord(ev[2], st));
-    if ((rc = launch_sb2st(n, npad, 64, nl, b.AB, b.d, b.e, st, b.status))) return rc;
+    if ((rc = launch_sb2st(n, npad, 64, nl, b.AB, b.d, b.e, st, b.status, b.sbctl))) return rc;
     if (ev) BSP_HIP(hipEventRecord(ev[3], st));
     if ((rc = launch_bisect(n, npad, nl, b.d, b.e, d_Eout, n, st))) return rc;
     if (ev) BSP_HIP(hipEventRecord(ev[4], st));
@@ -242,7 +243,7 @@ static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, dou
     BSP_HIP(hipEventRecord(p->ev[0], p->st));
     if ((rc = enqueue_assemble(p, l0, nl))) return rc;
     BSP_HIP(hipEventRecord(p->ev[1], p->st));
-    PipeBufs pb{p->d_UB, p->d_rdiag, p->d_Y, p->d_C, p->d_AB, p->d_d, p->d_e, p->d_work, p->d_info, p->d_status};
+    PipeBufs pb{p->d_UB, p->d_rdiag, p->d_Y, p->d_C, p->d_AB, p->d_d, p->d_e, p->d_work, p->d_info, p->d_status, p->d_sbctl};
     double *Eout = E_dev_out ? E_dev_out : p->d_E;
     if ((rc = pipeline_enqueue(n, np, h.k, nl, p->d_SB, p->d_HB, pb, Eout, p->st, &p->ev[1]))) return rc;
     if (E_dev_out)   // keep a copy for bspatom_eigvec

@@ -81,8 +81,11 @@ void sy2sb_carve(void *base, int npad, int nb, int batch, Sy2sbWork *w);
 int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipStream_t st);
 int launch_extract_band(int npad, int nb, int batch, const double *d_A, double *d_AB, hipStream_t st);
 // sb2st.hip
+// ctl: device scratch of sb2st_ctl_bytes(batch) bytes owned by the caller (per problem); nullptr -> a
+// process-wide buffer (stage-level entry points only).
+size_t sb2st_ctl_bytes(int batch);
 int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, double *d_e,
-                 hipStream_t st, int *d_status = nullptr);
+                 hipStream_t st, int *d_status = nullptr, void *ctl = nullptr);
 // tridiag.hip
 int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_e, double *d_w,
                   long ldw, hipStream_t st);
@@ -103,6 +106,7 @@ struct PipeBufs {
     void *work;
     int *info;
     int *status = nullptr;   // device word set to a BSP_ERR_* code by kernels that detect a failure
+    void *sbctl = nullptr;   // sb2st pairing/progress control block (sb2st_ctl_bytes(nl))
 };
 size_t pipe_bytes_per_channel(int npad);
 int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const double *d_HB,

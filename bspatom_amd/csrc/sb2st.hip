@@ -1360,19 +1360,26 @@ __global__ __launch_bounds__(256) void sb2st_kernel_v6(int n, int npad, int batc
     }
 }
 
-int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st, int *d_status)
+size_t sb2st_ctl_bytes(int batch) { return (size_t)batch * sizeof(Sb6Ctl); }
+
+int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st, int *d_status,
+                 void *ctl)
 {
     if (b != SB) return BSP_ERR_ARG;
     static int ver = -1;
     if (ver < 0) { const char *e = getenv("BSP_SB2ST_VERSION"); ver = e ? atoi(e) : 6; }
     if (ver == 1) hipLaunchKernelGGL(sb2st_kernel, dim3(batch), dim3(256), 0, st, n, npad, d_AB, d_d, d_e);
     else if (ver == 6) {
-        static Sb6Ctl *d_ctl = nullptr;
+        static Sb6Ctl *s_ctl = nullptr;
         static int cap = 0;
-        if (cap < batch) {
-            if (d_ctl) hipFree(d_ctl);
-            BSP_HIP(hipMalloc(reinterpret_cast<void **>(&d_ctl), (size_t)batch * sizeof(Sb6Ctl)));
-            cap = batch;
+        Sb6Ctl *d_ctl = static_cast<Sb6Ctl *>(ctl);
+        if (!d_ctl) {
+            if (cap < batch) {
+                if (s_ctl) hipFree(s_ctl);
+                BSP_HIP(hipMalloc(reinterpret_cast<void **>(&s_ctl), (size_t)batch * sizeof(Sb6Ctl)));
+                cap = batch;
+            }
+            d_ctl = s_ctl;
         }
         BSP_HIP(hipMemsetAsync(d_ctl, 0, (size_t)batch * sizeof(Sb6Ctl), st));
         const int nblk = ((batch + 7) / 8) * 16;
