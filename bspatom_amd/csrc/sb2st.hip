@@ -1360,6 +1360,535 @@ __global__ __launch_bounds__(256) void sb2st_kernel_v6(int n, int npad, int batc
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// v7: TWO SWEEPS PER PASS WITH ON-CHIP FORWARDING (halves the HBM traffic of bulge chasing).
+// One 512-thread workgroup per channel.  Half A (waves 0-3) runs sweep s = 0, 2, 4, ...: it loads its
+// tiles from HBM (prefetched, as v3) but writes its UPDATED tiles to LDS exchange slots instead of HBM.
+// Half B (waves 4-7) runs sweep s+1 two items behind: its item-k tiles are A's updated tiles of items
+// k and k+1 shifted by one row and one column (checked bit-for-bit in tools/proto_forward.py), which it
+// assembles from the slots; only B stores to HBM.  Per item pair 48 KB are loaded and 48 KB stored
+// instead of 96 + 96.  A's only HBM stores are the finished column s and the diagonal entry (s+1,s+1).
+// Both halves execute exactly five barriers per super-step in two separate straight-line loops.
+constexpr int SB7_MAX_STALL = 4096;  // super-steps B may wait for A before the kernel gives up (a sweep has <= n/64 + 3)
+constexpr int SB7_LAG_HBM = 6;      // A's next sweep may read what B stored this many items earlier
+
+// per-half scratch: as Sb3Lds, but R1 (written in P1, read in P2) shares its storage with R2 (written in
+// P3, read in P4) -- barriers 2 and 4/0 separate the two lifetimes -- so that both halves plus the
+// exchange slots fit the CU's 160 KB of LDS
+struct Sb7Lds {
+    double va[SB], vb[SB], w[SB], z[SB], pv[SB], x0[SB];
+    union { double R1[16][RLD]; double R2[16][RLD]; };
+    double R3[16][RLD], R4[16][RLD];
+    double sc[8];
+};
+// Exchange frames.  Sweep s+1's item-k tiles B'_k, D'_k are A's item-k tiles shifted by one row and one
+// column, with the first column of A's D_k as the last column of B'_k, and the first row of A's item k+1
+// tiles as their LAST row.  A stores its updated tiles UNSHIFTED, B reads them at (i+1, j+1):
+//   FB[f][j][i]   = B_k(i, j)            (j < SB), written by every thread, zero outside the tile
+//   FB[f][SB][i]  = D_k(i, 0)            the column that becomes B'_k's last one (and sweep s+1's x for k = 0)
+//   FB[f][SB][L2] = B_{k+1}(0, 0)        written by A's item k+1 (its L equals this item's L2)
+//   FD<f>(i, j)   = D_k(i, j), i >= j;   FD<f>(L2, j) = B_{k+1}(0, j) (j >= 1),  FD<f>(L2, L2) = D_{k+1}(0, 0)
+// The frame index f is the PARITY OF THE SUPER-STEP in which A runs the item -- a compile-time constant in
+// the unrolled pair, so every LDS address is a lane base plus an immediate.  B runs item k exactly two
+// super-steps after A (same parity; checked through the tags).
+struct Sb7Shared {
+    Sb7Lds S[2];
+    double FB[2][SB + 1][TLD];
+    double FD[SB + 2][TLD];         // lower triangles incl. row SB of both frames: frame 0 at FD[j][i], frame 1 at FD[i+1][j]
+    int tag[2][2];                  // per frame: sweep and item of the A item that wrote its main part
+    int sweep[2], done[2], fin[2], viol, abort;
+};
+static_assert(sizeof(Sb7Shared) <= 160 * 1024, "both halves' scratch and the exchange frames must fit the CU's LDS");
+static_assert(TLD >= SB + 1, "row SB of the frames");
+
+template <int F>
+__device__ __forceinline__ double &fd_ref(Sb7Shared &SH, int i, int j)
+{
+    return F == 0 ? SH.FD[j][i] : SH.FD[i + 1][j];
+}
+
+// element offset of tile entry (ib + 16 ri, j0 + cj) from the tile's base in band storage (ld 2*SB - 1 per column)
+#define SB7_OFF(ri, cj) (o0 + (unsigned)((cj) * (2 * SB - 1) + 16 * (ri)))
+
+// diagnostic cycle stamps of v7 (DIAG instantiation only; never part of a timed or shipped run)
+struct Diag7 { long long acc[10]; long long tlast; };
+#define SB7_STAMP(k)                                                             \
+    if (DIAG) {                                                                  \
+        const long long tnow_ = (long long)__builtin_amdgcn_s_memtime();         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       \
+        dg.acc[k] += tnow_ - dg.tlast;                                           \
+        dg.tlast = tnow_;                                                        \
+    }
+
+// ---- half A: one super-step -------------------------------------------------------------------
+template <int PAR, int DIAG>
+__device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared &SH, int htid, int ib, int j0,
+                                              unsigned o0, unsigned low, int n,
+                                              int &state, int &sw, int &done, ChaseState &st, Diag7 &dg, double &xpre,
+                                              double (&Bc)[4][4], double (&Dc)[4][4], double (&Bn)[4][4], double (&Dn)[4][4])
+{
+    constexpr int LD = 2 * SB;
+    Sb7Lds &S = SH.S[0];
+    const double *vc = PAR ? S.vb : S.va;
+    double *vn = PAR ? S.va : S.vb;
+    const int jb = j0 >> 2;
+    SB7_STAMP(9);
+    lds_barrier();                                           // barrier 0
+    SB7_STAMP(0);
+    int act = ACT_IDLE;
+    {
+        const int osw = SH.sweep[1], odn = SH.done[1], ofin = SH.fin[1];
+        if (state == 1) {
+            // B must be (a) SB7_LAG_HBM items into sweep sw-1, so that the tiles this sweep loads are in HBM, and
+            // (b) at most one item from its end: item 0 of this sweep (next super-step) overwrites frame 0
+            const int kb = (n - sw + SB - 1) / SB;           // items of sweep sw-1
+            const int need = (kb - 2 > SB7_LAG_HBM) ? kb - 2 : SB7_LAG_HBM;
+            const bool ok = (sw == 0) || ofin || (osw > sw - 1) || (osw == sw - 1 && odn >= need);
+            act = ok ? ACT_PRELOAD : ACT_IDLE;
+        } else if (state == 2) act = ACT_ITEM0;
+        else if (state == 3) act = ACT_CHASE;
+    }
+    if ((SH.fin[0] && SH.fin[1]) || SH.abort) { state = -1; return; }
+    const bool comp = (act >= ACT_ITEM0);
+    const bool item0 = (act == ACT_ITEM0);
+    const int L0 = (n - 1 - sw < SB) ? (n - 1 - sw) : SB;
+    if (item0) { st.r0 = sw + 1; st.L = 0; st.L2 = L0; st.tau = 0.0; }
+    const int r0 = comp ? st.r0 : 0, L = comp ? st.L : 0, L2 = comp ? st.L2 : 0, rn = r0 + L;
+    int pr0, pL, pL2;
+    bool have_pf;
+    if (act == ACT_PRELOAD) { pr0 = sw + 1; pL = 0; pL2 = L0; have_pf = true; }
+    else {
+        have_pf = comp && (rn + L2 < n);
+        pr0 = rn; pL = L2; pL2 = have_pf ? ((n - (rn + L2) < SB) ? (n - (rn + L2)) : SB) : 0;
+    }
+    // ---- P1: prefetch from HBM (branch-free), partial w ----
+    {
+        const double *__restrict__ Bb = have_pf ? (AB + ((size_t)pr0 * LD + pL)) : AB;
+        const double *__restrict__ Db = have_pf ? (AB + (size_t)(pr0 + pL) * LD) : AB;
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const int i = SB3_ROW(ri), j = SB3_COL(cj);
+                const bool okb = have_pf && (i < pL2) && (j < pL);
+                const bool okd = have_pf && ((low >> (ri * 4 + cj)) & 1u) && (i < pL2);
+                const double bv = Bb[okb ? SB7_OFF(ri, cj) : 0u];
+                const double dv = Db[okd ? SB7_OFF(ri, cj) : 0u];
+                Bn[ri][cj] = okb ? bv : 0.0;
+                Dn[ri][cj] = okd ? dv : 0.0;
+            }
+        if (htid < 64) {
+            const bool okx = (act == ACT_PRELOAD) && (htid < L0);
+            const double xr = AB[okx ? ((size_t)sw * LD + 1 + htid) : 0];
+            xpre = (act == ACT_PRELOAD) ? (okx ? xr : 0.0) : xpre;
+        }
+        double vcj[4];
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) vcj[cj] = vc[j0 + cj];
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            double a = 0.0;
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj) a += Bc[ri][cj] * vcj[cj];
+            S.R1[jb][SB3_ROW(ri)] = a;
+        }
+        if (jb == 0) {
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) S.x0[SB3_ROW(ri)] = Bc[ri][0];
+        }
+    }
+    SB7_STAMP(1);
+    lds_barrier();
+    SB7_STAMP(2);
+    // ---- P2 ----
+    if (htid < 64) {
+        const int i = htid;
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += S.R1[q][i];
+        const double wi = item0 ? 0.0 : st.tau * a;
+        const double xc = item0 ? xpre : (S.x0[i] - wi * vc[0]);
+        const double xi = (i < L2) ? xc : 0.0;
+        double beta2, tau2;
+        const double vi = wave_house(xi, i, L2, &beta2, &tau2);
+        const double sdot = wave_sum(vi * wi);
+        S.w[i] = wi; vn[i] = vi;
+        if (i == 0) { S.sc[1] = beta2; S.sc[2] = tau2; S.sc[3] = sdot; }
+    }
+    SB7_STAMP(3);
+    lds_barrier();
+    SB7_STAMP(4);
+    const double beta2 = S.sc[1], tau2 = S.sc[2], sdot = S.sc[3];
+    // ---- P3 ----
+    double vni[4], vnj[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { vni[x] = vn[SB3_ROW(x)]; vnj[x] = vn[j0 + x]; }
+    {
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+            double a = 0.0;
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) a += vni[ri] * Bc[ri][cj];
+            S.R2[ib][j0 + cj] = a;
+        }
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            double a = 0.0;
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj) a += Dc[ri][cj] * vnj[cj];
+            S.R3[jb][SB3_ROW(ri)] = a;
+        }
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+            double a = 0.0;
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) a += (SB3_ROW(ri) != j0 + cj) ? Dc[ri][cj] * vni[ri] : 0.0;
+            S.R4[ib][j0 + cj] = a;
+        }
+    }
+    SB7_STAMP(5);
+    lds_barrier();
+    SB7_STAMP(6);
+    // ---- P4 ----
+    if (htid < 64) {
+        const int j = htid;
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += S.R2[q][j];
+        S.z[j] = tau2 * (a - sdot * vc[j]);
+    } else if (htid < 128) {
+        const int i = htid - 64;
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += S.R3[q][i] + S.R4[q][i];
+        const double pi = tau2 * a;
+        const double dot = wave_sum(pi * vn[i]);
+        S.pv[i] = pi + (-0.5 * tau2 * dot) * vn[i];
+    }
+    SB7_STAMP(7);
+    lds_barrier();
+    SB7_STAMP(8);
+    // ---- P5: updated tiles -> exchange frames; only the finished entries go to HBM ----
+    if (comp) {
+        const int item = item0 ? 0 : done;
+        constexpr int f = PAR, g = PAR ^ 1;
+        // no partner sweep s+1 (end of the matrix): nobody picks the tiles up from LDS, store them instead
+        const int Lp = (n - 2 - sw < SB) ? (n - 2 - sw) : SB;
+        const bool fwd = (sw + 1 < n - 2) && (Lp >= 2);
+        double *__restrict__ Bb = AB + ((size_t)r0 * LD + L);
+        double *__restrict__ Db = AB + (size_t)rn * LD;
+        {   // B tile (two passes keep the register pressure of each below the 256 of a 512-thread workgroup)
+            double wi[4], zj[4], vcj[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { wi[x] = S.w[SB3_ROW(x)]; zj[x] = S.z[j0 + x]; vcj[x] = vc[j0 + x]; }
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri) {
+                    const int i = SB3_ROW(ri), j = j0 + cj;
+                    const bool inb = (i < L2) && (j < L);
+                    double bnew = Bc[ri][cj] - (wi[ri] * vcj[cj] + vni[ri] * zj[cj]);
+                    if (j == 0) bnew = (i == 0) ? beta2 : 0.0;
+                    bnew = inb ? bnew : 0.0;
+                    if (fwd) {
+                        SH.FB[f][j][i] = bnew;
+                        if (ri == 0 && ib == 0 && inb) {      // row 0 of this item = last row of item k-1's frame
+                            if (j >= 1) fd_ref<g>(SH, L, j) = bnew; else SH.FB[g][SB][L] = bnew;
+                        }
+                        // the annihilated column is outside every tile of sweep s+1 but inside item k-1's tile of
+                        // sweep s+2, and HBM still holds sweep s-1's bulge there: the zeros must land
+                        if (cj == 0 && jb == 0 && i >= 1 && inb) Bb[SB7_OFF(ri, 0)] = 0.0;
+                    } else if (inb) Bb[SB7_OFF(ri, cj)] = bnew;
+                }
+        }
+        asm volatile("" ::: "memory");
+        {   // D tile
+            double pi[4], pj[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { pi[x] = S.pv[SB3_ROW(x)]; pj[x] = S.pv[j0 + x]; }
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri) {
+                    const int i = SB3_ROW(ri), j = j0 + cj;
+                    const bool lw = (low >> (ri * 4 + cj)) & 1u;
+                    const bool isl = lw && (i < L2);
+                    const double dnew = isl ? (Dc[ri][cj] - (vni[ri] * pj[cj] + pi[ri] * vnj[cj])) : 0.0;
+                    if (fwd) {
+                        if (lw) fd_ref<f>(SH, i, j) = dnew;
+                        if (cj == 0 && jb == 0) SH.FB[f][SB][i] = dnew;   // first column: last column of B'_k / x of sweep s+1
+                        if (ri == 0 && cj == 0 && ib == 0 && jb == 0) {
+                            if (item0) AB[(size_t)rn * LD] = dnew;        // A(s+1, s+1) is final
+                            else fd_ref<g>(SH, L, L) = dnew;
+                        }
+                    } else if (isl) Db[SB7_OFF(ri, cj)] = dnew;
+                }
+        }
+        if (item0 && htid < L2) AB[(size_t)sw * LD + 1 + htid] = (htid == 0) ? beta2 : 0.0;   // finished column s
+        if (htid == 0) { SH.tag[f][0] = sw; SH.tag[f][1] = item; }
+    }
+    // ---- state update + publication ----
+    if (act == ACT_PRELOAD) state = 2;
+    else if (comp) {
+        const bool more = (rn + L2 < n);
+        st.r0 = rn; st.L = L2; st.L2 = pL2; st.tau = tau2;
+        done = item0 ? 1 : done + 1;
+        if (more) state = 3;
+        else {
+            sw += 2; done = 0;
+            const int Lnext = (n - 1 - sw < SB) ? (n - 1 - sw) : SB;
+            state = (sw < n - 2 && Lnext >= 2) ? 1 : 0;
+        }
+        if (htid == 0) { SH.sweep[0] = sw; SH.done[0] = done; if (state == 0) SH.fin[0] = 1; }
+    }
+}
+
+// ---- half B: one super-step -------------------------------------------------------------------
+template <int PAR, int DIAG>
+__device__ __forceinline__ void superstep_v7B(double *__restrict__ AB, Sb7Shared &SH, int htid, int ib, int j0,
+                                              unsigned o0, unsigned low, int n,
+                                              int &state, int &sw, int &done, int &stall, ChaseState &st, Diag7 &dg)
+{
+    constexpr int LD = 2 * SB;
+    Sb7Lds &S = SH.S[1];
+    const double *vc = PAR ? S.vb : S.va;
+    double *vn = PAR ? S.va : S.vb;
+    const int jb = j0 >> 2;
+    SB7_STAMP(9);
+    lds_barrier();                                           // barrier 0
+    SB7_STAMP(0);
+    // item j of sweep sw needs A's items j and j+1 of sweep sw-1 (or A finished that sweep)
+    int act = ACT_IDLE;
+    if (state != 0) {
+        const int asw = SH.sweep[0], adn = SH.done[0], afin = SH.fin[0];
+        const int j = (state == 2) ? 0 : done;
+        // ... and the frame of this super-step's parity must be the one A filled with item j: true exactly two
+        // super-steps after A ran it (when A ends its sweep with item j, one step after is too early)
+        const bool ok = (afin || (asw > sw - 1) || (asw == sw - 1 && adn >= j + 2)) &&
+                        (SH.tag[PAR][0] == sw - 1 && SH.tag[PAR][1] == j);
+        if (ok) { act = (state == 2) ? ACT_ITEM0 : ACT_CHASE; stall = 0; }
+        else ++stall;
+    }
+    if ((SH.fin[0] && SH.fin[1]) || SH.abort) { state = -1; return; }
+    const bool comp = (act >= ACT_ITEM0);
+    const bool item0 = (act == ACT_ITEM0);
+    const int L0 = (n - 1 - sw < SB) ? (n - 1 - sw) : SB;
+    if (item0) { st.r0 = sw + 1; st.L = 0; st.L2 = L0; st.tau = 0.0; }
+    const int r0 = comp ? st.r0 : 0, L = comp ? st.L : 0, L2 = comp ? st.L2 : 0, rn = r0 + L;
+    const int item = item0 ? 0 : done;
+    // ---- P1: this item's tiles from frame item & 1 ----
+    double Bc[4][4], Dc[4][4];
+    double xcol = 0.0;
+    {
+        constexpr int f = PAR;
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const int i = SB3_ROW(ri), j = SB3_COL(cj);
+                // row SB-1 of B' left of its last column lies outside even the bulged band (A never writes it)
+                const bool okb = comp && (i < L2) && (j < L) && !(i == SB - 1 && j < L - 1);
+                const bool okd = comp && (i < L2) && (j <= i);
+                const double bv = SH.FB[f][j + 1][i + 1];
+                const double cv = SH.FB[f][SB][i + 1];
+                const double dv = fd_ref<f>(SH, i + 1, j + 1);
+                Bc[ri][cj] = okb ? ((j == L - 1) ? cv : bv) : 0.0;
+                Dc[ri][cj] = okd ? dv : 0.0;
+            }
+        if (htid < 64) { const double xv = SH.FB[f][SB][htid + 1]; xcol = (item0 && htid < L2) ? xv : 0.0; }
+        double vcj[4];
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) vcj[cj] = vc[j0 + cj];
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            double a = 0.0;
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj) a += Bc[ri][cj] * vcj[cj];
+            S.R1[jb][SB3_ROW(ri)] = a;
+        }
+        if (jb == 0) {
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) S.x0[SB3_ROW(ri)] = Bc[ri][0];
+        }
+    }
+    SB7_STAMP(1);
+    lds_barrier();
+    SB7_STAMP(2);
+    // ---- P2 ----
+    if (htid < 64) {
+        const int i = htid;
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += S.R1[q][i];
+        const double wi = item0 ? 0.0 : st.tau * a;
+        const double xc = item0 ? xcol : (S.x0[i] - wi * vc[0]);
+        const double xi = (i < L2) ? xc : 0.0;
+        double beta2, tau2;
+        const double vi = wave_house(xi, i, L2, &beta2, &tau2);
+        const double sdot = wave_sum(vi * wi);
+        S.w[i] = wi; vn[i] = vi;
+        if (i == 0) { S.sc[1] = beta2; S.sc[2] = tau2; S.sc[3] = sdot; }
+    }
+    SB7_STAMP(3);
+    lds_barrier();
+    SB7_STAMP(4);
+    const double beta2 = S.sc[1], tau2 = S.sc[2], sdot = S.sc[3];
+    // ---- P3 ----
+    double vni[4], vnj[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { vni[x] = vn[SB3_ROW(x)]; vnj[x] = vn[j0 + x]; }
+    {
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+            double a = 0.0;
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) a += vni[ri] * Bc[ri][cj];
+            S.R2[ib][j0 + cj] = a;
+        }
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            double a = 0.0;
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj) a += Dc[ri][cj] * vnj[cj];
+            S.R3[jb][SB3_ROW(ri)] = a;
+        }
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+            double a = 0.0;
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) a += (SB3_ROW(ri) != j0 + cj) ? Dc[ri][cj] * vni[ri] : 0.0;
+            S.R4[ib][j0 + cj] = a;
+        }
+    }
+    SB7_STAMP(5);
+    lds_barrier();
+    SB7_STAMP(6);
+    // ---- P4 ----
+    if (htid < 64) {
+        const int j = htid;
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += S.R2[q][j];
+        S.z[j] = tau2 * (a - sdot * vc[j]);
+    } else if (htid < 128) {
+        const int i = htid - 64;
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += S.R3[q][i] + S.R4[q][i];
+        const double pi = tau2 * a;
+        const double dot = wave_sum(pi * vn[i]);
+        S.pv[i] = pi + (-0.5 * tau2 * dot) * vn[i];
+    }
+    SB7_STAMP(7);
+    lds_barrier();
+    SB7_STAMP(8);
+    // ---- P5: results to HBM ----
+    {
+        double wi[4], zj[4], vcj[4], pi[4], pj[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            wi[x] = S.w[SB3_ROW(x)]; zj[x] = S.z[j0 + x]; vcj[x] = vc[j0 + x]; pi[x] = S.pv[SB3_ROW(x)]; pj[x] = S.pv[j0 + x];
+        }
+        double *__restrict__ Bb = AB + ((size_t)r0 * LD + L);
+        double *__restrict__ Db = AB + (size_t)rn * LD;
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const int i = SB3_ROW(ri), j = j0 + cj;
+                double bnew = Bc[ri][cj] - (wi[ri] * vcj[cj] + vni[ri] * zj[cj]);
+                if (j == 0) bnew = (i == 0) ? beta2 : 0.0;
+                if (i < L2 && j < L) Bb[SB7_OFF(ri, cj)] = bnew;
+                if (((low >> (ri * 4 + cj)) & 1u) && i < L2)
+                    Db[SB7_OFF(ri, cj)] = Dc[ri][cj] - (vni[ri] * pj[cj] + pi[ri] * vnj[cj]);
+            }
+        if (item0 && htid < L2) AB[(size_t)sw * LD + 1 + htid] = (htid == 0) ? beta2 : 0.0;
+    }
+    if (comp) {
+        const bool more = (rn + L2 < n);
+        const int nL2 = more ? ((n - (rn + L2) < SB) ? (n - (rn + L2)) : SB) : 0;
+        st.r0 = rn; st.L = L2; st.L2 = nL2; st.tau = tau2;
+        done = item0 ? 1 : done + 1;
+        if (more) state = 3;
+        else {
+            sw += 2; done = 0;
+            const int Lnext = (n - 1 - sw < SB) ? (n - 1 - sw) : SB;
+            state = (sw < n - 2 && Lnext >= 2) ? 2 : 0;
+        }
+        if (htid == 0) { SH.sweep[1] = sw; SH.done[1] = done; if (state == 0) SH.fin[1] = 1; }
+    }
+    // B missed its window (cannot happen while the halves run in lock-step): give up instead of spinning;
+    // written after the last barrier, so that every wave sees it after barrier 0 of the next super-step
+    if (stall > SB7_MAX_STALL && htid == 0) { SH.abort = 1; SH.viol = 1; }
+}
+
+template <int DIAG>
+__global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, double *ABall, double *dall, double *eall, int *status,
+                                                       long long *diag)
+{
+    Diag7 dg;
+    if (DIAG) { for (int q = 0; q < 10; ++q) dg.acc[q] = 0; dg.tlast = (long long)__builtin_amdgcn_s_memtime(); }
+    extern __shared__ __attribute__((aligned(16))) unsigned char sb7_raw[];
+    Sb7Shared &SH = *reinterpret_cast<Sb7Shared *>(sb7_raw);
+    constexpr int LD = 2 * SB;
+    const int tid = threadIdx.x, h = tid >> 8, htid = tid & 255, lane = tid & 63, hwave = htid >> 6;
+    const int ib = lane & 15, jb = (lane >> 4) + 4 * hwave;
+    const int j0 = 4 * jb;
+    const unsigned o0 = (unsigned)(j0 * (LD - 1) + ib);
+    unsigned low = 0;
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri)
+            if (SB3_ROW(ri) >= j0 + cj) low |= 1u << (ri * 4 + cj);
+    const size_t ch = blockIdx.x;
+    double *AB = ABall + ch * ab_stride(npad);
+    if (tid == 0) { SH.viol = 0; SH.abort = 0; }
+    if (htid == 0) {
+        const int L0 = (n - 1 - h < SB) ? (n - 1 - h) : SB;
+        const bool any = (h < n - 2) && (L0 >= 2);
+        SH.sweep[h] = h; SH.done[h] = 0; SH.fin[h] = any ? 0 : 1;
+        SH.tag[h][0] = -1; SH.tag[h][1] = -1;
+    }
+    __syncthreads();
+    int sw = h, done = 0;
+    ChaseState st; st.r0 = 0; st.L = 0; st.L2 = 0; st.L3 = 0; st.tau = 0.0;
+    if (h == 0) {
+        int state = SH.fin[0] ? 0 : 1;
+        double xpre = 0.0;
+        double B0[4][4], D0[4][4], B1[4][4], D1[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { B0[a][c] = 0.0; D0[a][c] = 0.0; B1[a][c] = 0.0; D1[a][c] = 0.0; }
+        for (;;) {
+            superstep_v7A<0, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, st, dg, xpre, B0, D0, B1, D1);
+            if (state < 0) break;
+            superstep_v7A<1, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, st, dg, xpre, B1, D1, B0, D0);
+            if (state < 0) break;
+        }
+    } else {
+        int state = SH.fin[1] ? 0 : 2, stall = 0;
+        for (;;) {
+            superstep_v7B<0, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, stall, st, dg);
+            if (state < 0) break;
+            superstep_v7B<1, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, stall, st, dg);
+            if (state < 0) break;
+        }
+    }
+    if (DIAG && lane == 0 && blockIdx.x == 0) {
+        for (int q = 0; q < 10; ++q) diag[(tid >> 6) * 10 + q] = dg.acc[q];
+    }
+    __syncthreads();
+    if (tid == 0 && SH.viol && status) atomicExch(status, BSP_ERR_HIP);      // exchange-frame protocol violated
+    double *d = dall + ch * (size_t)npad, *e = eall + ch * (size_t)npad;
+    for (int j = tid; j < n; j += 512) {
+        d[j] = AB[(size_t)j * LD];
+        e[j] = (j < n - 1) ? AB[(size_t)j * LD + 1] : 0.0;
+    }
+}
+
 size_t sb2st_ctl_bytes(int batch) { return (size_t)batch * sizeof(Sb6Ctl); }
 
 int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st, int *d_status,
@@ -1396,6 +1925,47 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
                     batch, nsolo, nerr, nw[0] / batch, nw[1] / batch, 100 * wc[0] / (tc[0] + 1), 100 * wc[1] / (tc[1] + 1),
                     tc[0] / batch / 1e6, tc[1] / batch / 1e6);
             if (nerr) return BSP_ERR_HIP;
+        }
+    }
+    else if (ver == 7) {
+        static bool attr7 = false;
+        if (!attr7) {
+            BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sb2st_kernel_v7<0>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sb2st_kernel_v7<1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr7 = true;
+        }
+        static int *d_chk = nullptr;
+        const bool chk = getenv("BSP_SB2ST_CHECK") != nullptr;
+        if (chk && !d_chk) BSP_HIP(hipMalloc(reinterpret_cast<void **>(&d_chk), sizeof(int)));
+        if (chk) BSP_HIP(hipMemsetAsync(d_chk, 0, sizeof(int), st));
+        static int diag7 = -1;
+        if (diag7 < 0) { const char *e = getenv("BSP_SB2ST_DIAG"); diag7 = e ? atoi(e) : 0; }
+        if (diag7) {
+            long long *dbuf = nullptr, h[80];
+            BSP_HIP(hipMalloc(reinterpret_cast<void **>(&dbuf), sizeof(h)));
+            hipLaunchKernelGGL(sb2st_kernel_v7<1>, dim3(batch), dim3(512), (sizeof(Sb7Shared) + 1023) / 1024 * 1024, st, n, npad,
+                               d_AB, d_d, d_e, chk ? d_chk : d_status, dbuf);
+            BSP_HIP(hipStreamSynchronize(st));
+            BSP_HIP(hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost));
+            hipFree(dbuf);
+            static const char *nm[10] = {"barrier0", "P1", "barrier1", "P2", "barrier2", "P3", "barrier3", "P4", "barrier4", "P5+upd"};
+            for (int wv = 0; wv < 8; ++wv) {
+                long long tot = 0;
+                for (int q = 0; q < 10; ++q) tot += h[wv * 10 + q];
+                fprintf(stderr, "sb2st v7 diag wave %d (Mcycles %.1f):", wv, tot / 1e6);
+                for (int q = 0; q < 10; ++q) fprintf(stderr, " [%s %.1f%%]", nm[q], 100.0 * h[wv * 10 + q] / (double)tot);
+                fprintf(stderr, "\n");
+            }
+        } else
+        hipLaunchKernelGGL(sb2st_kernel_v7<0>, dim3(batch), dim3(512), (sizeof(Sb7Shared) + 1023) / 1024 * 1024, st, n, npad,
+                           d_AB, d_d, d_e, chk ? d_chk : d_status, (long long *)nullptr);
+        if (chk) {
+            int hv = 0;
+            BSP_HIP(hipStreamSynchronize(st));
+            BSP_HIP(hipMemcpy(&hv, d_chk, sizeof(int), hipMemcpyDeviceToHost));
+            if (hv) { fprintf(stderr, "bspatom: sb2st v7 exchange-slot violations (status %d)\n", hv); return BSP_ERR_HIP; }
         }
     }
     else if (ver == 4) {
