@@ -1412,7 +1412,7 @@ __device__ __forceinline__ double &fd_ref(Sb7Shared &SH, int i, int j)
 #define SB7_OFF(ri, cj) (o0 + (unsigned)((cj) * (2 * SB - 1) + 16 * (ri)))
 
 // diagnostic cycle stamps of v7 (DIAG instantiation only; never part of a timed or shipped run)
-struct Diag7 { long long acc[10]; long long tlast; };
+struct Diag7 { long long acc[12]; long long tlast; };
 #define SB7_STAMP(k)                                                             \
     if (DIAG) {                                                                  \
         const long long tnow_ = (long long)__builtin_amdgcn_s_memtime();         \
@@ -1421,43 +1421,33 @@ struct Diag7 { long long acc[10]; long long tlast; };
         dg.tlast = tnow_;                                                        \
     }
 
-// ---- half A: one super-step -------------------------------------------------------------------
-template <int PAR, int DIAG>
-__device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared &SH, int htid, int ib, int j0,
-                                              unsigned o0, unsigned low, int n,
+// ---- half A: one super-step after barrier 0.  FAST: an interior chase item (64 x 64 tiles, a full successor,
+// a partner sweep) -- every range mask is true and folds away; the general instantiation handles the rest.
+template <int PAR, int FAST, int DIAG>
+__device__ __forceinline__ void body_v7A(double *__restrict__ AB, Sb7Shared &SH, int htid_, int ib_, int j0_,
+                                              unsigned o0_, unsigned low_, int n,
                                               int &state, int &sw, int &done, ChaseState &st, Diag7 &dg, double &xpre,
-                                              double (&Bc)[4][4], double (&Dc)[4][4], double (&Bn)[4][4], double (&Dn)[4][4])
+                                              double (&Bc)[4][4], double (&Dc)[4][4], double (&Bn)[4][4], double (&Dn)[4][4], int act)
 {
     constexpr int LD = 2 * SB;
     Sb7Lds &S = SH.S[0];
     const double *vc = PAR ? S.vb : S.va;
     double *vn = PAR ? S.va : S.vb;
+    // the lane constants are re-derived per super-step: kept live across the whole loop (with everything the
+    // compiler pre-computes from them: masks, row indices, LDS addresses) they do not fit the 256 registers
+    int htid = htid_, ib = ib_, j0 = j0_;
+    unsigned o0 = o0_, low = low_;
+    asm volatile("" : "+v"(htid), "+v"(ib), "+v"(j0), "+v"(o0), "+v"(low));
     const int jb = j0 >> 2;
-    SB7_STAMP(9);
-    lds_barrier();                                           // barrier 0
-    SB7_STAMP(0);
-    int act = ACT_IDLE;
-    {
-        const int osw = SH.sweep[1], odn = SH.done[1], ofin = SH.fin[1];
-        if (state == 1) {
-            // B must be (a) SB7_LAG_HBM items into sweep sw-1, so that the tiles this sweep loads are in HBM, and
-            // (b) at most one item from its end: item 0 of this sweep (next super-step) overwrites frame 0
-            const int kb = (n - sw + SB - 1) / SB;           // items of sweep sw-1
-            const int need = (kb - 2 > SB7_LAG_HBM) ? kb - 2 : SB7_LAG_HBM;
-            const bool ok = (sw == 0) || ofin || (osw > sw - 1) || (osw == sw - 1 && odn >= need);
-            act = ok ? ACT_PRELOAD : ACT_IDLE;
-        } else if (state == 2) act = ACT_ITEM0;
-        else if (state == 3) act = ACT_CHASE;
-    }
-    if ((SH.fin[0] && SH.fin[1]) || SH.abort) { state = -1; return; }
-    const bool comp = (act >= ACT_ITEM0);
-    const bool item0 = (act == ACT_ITEM0);
+    const bool comp = FAST ? true : (act >= ACT_ITEM0);
+    const bool item0 = FAST ? false : (act == ACT_ITEM0);
     const int L0 = (n - 1 - sw < SB) ? (n - 1 - sw) : SB;
     if (item0) { st.r0 = sw + 1; st.L = 0; st.L2 = L0; st.tau = 0.0; }
-    const int r0 = comp ? st.r0 : 0, L = comp ? st.L : 0, L2 = comp ? st.L2 : 0, rn = r0 + L;
+    const int r0 = comp ? st.r0 : 0, L = FAST ? SB : (comp ? st.L : 0), L2 = FAST ? SB : (comp ? st.L2 : 0), rn = r0 + L;
     int pr0, pL, pL2;
     bool have_pf;
-    if (act == ACT_PRELOAD) { pr0 = sw + 1; pL = 0; pL2 = L0; have_pf = true; }
+    if (FAST) { pr0 = rn; pL = SB; pL2 = SB; have_pf = true; }
+    else if (act == ACT_PRELOAD) { pr0 = sw + 1; pL = 0; pL2 = L0; have_pf = true; }
     else {
         have_pf = comp && (rn + L2 < n);
         pr0 = rn; pL = L2; pL2 = have_pf ? ((n - (rn + L2) < SB) ? (n - (rn + L2)) : SB) : 0;
@@ -1471,14 +1461,14 @@ __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared
 #pragma unroll
             for (int ri = 0; ri < 4; ++ri) {
                 const int i = SB3_ROW(ri), j = SB3_COL(cj);
-                const bool okb = have_pf && (i < pL2) && (j < pL);
-                const bool okd = have_pf && ((low >> (ri * 4 + cj)) & 1u) && (i < pL2);
+                const bool okb = FAST ? true : (have_pf && (i < pL2) && (j < pL));
+                const bool okd = ((low >> (ri * 4 + cj)) & 1u) && (FAST ? true : (have_pf && (i < pL2)));
                 const double bv = Bb[okb ? SB7_OFF(ri, cj) : 0u];
                 const double dv = Db[okd ? SB7_OFF(ri, cj) : 0u];
                 Bn[ri][cj] = okb ? bv : 0.0;
                 Dn[ri][cj] = okd ? dv : 0.0;
             }
-        if (htid < 64) {
+        if (!FAST) {                                          // every wave loads (a branch around a load drains vmcnt)
             const bool okx = (act == ACT_PRELOAD) && (htid < L0);
             const double xr = AB[okx ? ((size_t)sw * LD + 1 + htid) : 0];
             xpre = (act == ACT_PRELOAD) ? (okx ? xr : 0.0) : xpre;
@@ -1509,7 +1499,7 @@ __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared
         for (int q = 0; q < 16; ++q) a += S.R1[q][i];
         const double wi = item0 ? 0.0 : st.tau * a;
         const double xc = item0 ? xpre : (S.x0[i] - wi * vc[0]);
-        const double xi = (i < L2) ? xc : 0.0;
+        const double xi = (FAST || i < L2) ? xc : 0.0;
         double beta2, tau2;
         const double vi = wave_house(xi, i, L2, &beta2, &tau2);
         const double sdot = wave_sum(vi * wi);
@@ -1570,12 +1560,13 @@ __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared
     lds_barrier();
     SB7_STAMP(8);
     // ---- P5: updated tiles -> exchange frames; only the finished entries go to HBM ----
+    if (DIAG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SB7_STAMP(10); }
     if (comp) {
         const int item = item0 ? 0 : done;
         constexpr int f = PAR, g = PAR ^ 1;
         // no partner sweep s+1 (end of the matrix): nobody picks the tiles up from LDS, store them instead
         const int Lp = (n - 2 - sw < SB) ? (n - 2 - sw) : SB;
-        const bool fwd = (sw + 1 < n - 2) && (Lp >= 2);
+        const bool fwd = FAST ? true : ((sw + 1 < n - 2) && (Lp >= 2));
         double *__restrict__ Bb = AB + ((size_t)r0 * LD + L);
         double *__restrict__ Db = AB + (size_t)rn * LD;
         {   // B tile (two passes keep the register pressure of each below the 256 of a 512-thread workgroup)
@@ -1587,7 +1578,7 @@ __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared
 #pragma unroll
                 for (int ri = 0; ri < 4; ++ri) {
                     const int i = SB3_ROW(ri), j = j0 + cj;
-                    const bool inb = (i < L2) && (j < L);
+                    const bool inb = FAST ? true : ((i < L2) && (j < L));
                     double bnew = Bc[ri][cj] - (wi[ri] * vcj[cj] + vni[ri] * zj[cj]);
                     if (j == 0) bnew = (i == 0) ? beta2 : 0.0;
                     bnew = inb ? bnew : 0.0;
@@ -1613,7 +1604,7 @@ __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared
                 for (int ri = 0; ri < 4; ++ri) {
                     const int i = SB3_ROW(ri), j = j0 + cj;
                     const bool lw = (low >> (ri * 4 + cj)) & 1u;
-                    const bool isl = lw && (i < L2);
+                    const bool isl = lw && (FAST ? true : (i < L2));
                     const double dnew = isl ? (Dc[ri][cj] - (vni[ri] * pj[cj] + pi[ri] * vnj[cj])) : 0.0;
                     if (fwd) {
                         if (lw) fd_ref<f>(SH, i, j) = dnew;
@@ -1625,13 +1616,13 @@ __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared
                     } else if (isl) Db[SB7_OFF(ri, cj)] = dnew;
                 }
         }
-        if (item0 && htid < L2) AB[(size_t)sw * LD + 1 + htid] = (htid == 0) ? beta2 : 0.0;   // finished column s
+        if (!FAST && item0 && htid < L2) AB[(size_t)sw * LD + 1 + htid] = (htid == 0) ? beta2 : 0.0;   // finished column s
         if (htid == 0) { SH.tag[f][0] = sw; SH.tag[f][1] = item; }
     }
     // ---- state update + publication ----
-    if (act == ACT_PRELOAD) state = 2;
+    if (!FAST && act == ACT_PRELOAD) state = 2;
     else if (comp) {
-        const bool more = (rn + L2 < n);
+        const bool more = FAST ? true : (rn + L2 < n);
         st.r0 = rn; st.L = L2; st.L2 = pL2; st.tau = tau2;
         done = item0 ? 1 : done + 1;
         if (more) state = 3;
@@ -1644,38 +1635,56 @@ __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared
     }
 }
 
-// ---- half B: one super-step -------------------------------------------------------------------
+// ---- half A: one super-step -------------------------------------------------------------------
 template <int PAR, int DIAG>
-__device__ __forceinline__ void superstep_v7B(double *__restrict__ AB, Sb7Shared &SH, int htid, int ib, int j0,
+__device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared &SH, int htid, int ib, int j0,
                                               unsigned o0, unsigned low, int n,
-                                              int &state, int &sw, int &done, int &stall, ChaseState &st, Diag7 &dg)
+                                              int &state, int &sw, int &done, ChaseState &st, Diag7 &dg, double &xpre,
+                                              double (&Bc)[4][4], double (&Dc)[4][4], double (&Bn)[4][4], double (&Dn)[4][4])
+{
+    SB7_STAMP(9);
+    lds_barrier();                                           // barrier 0
+    SB7_STAMP(0);
+    int act = ACT_IDLE;
+    {
+        const int osw = SH.sweep[1], odn = SH.done[1], ofin = SH.fin[1];
+        if (state == 1) {
+            // B must be (a) SB7_LAG_HBM items into sweep sw-1, so that the tiles this sweep loads are in HBM, and
+            // (b) at most one item from its end: item 0 of this sweep (next super-step) overwrites frame 0
+            const int kb = (n - sw + SB - 1) / SB;           // items of sweep sw-1
+            const int need = (kb - 2 > SB7_LAG_HBM) ? kb - 2 : SB7_LAG_HBM;
+            const bool ok = (sw == 0) || ofin || (osw > sw - 1) || (osw == sw - 1 && odn >= need);
+            act = ok ? ACT_PRELOAD : ACT_IDLE;
+        } else if (state == 2) act = ACT_ITEM0;
+        else if (state == 3) act = ACT_CHASE;
+    }
+    if ((SH.fin[0] && SH.fin[1]) || SH.abort) { state = -1; return; }
+    const bool fast = (act == ACT_CHASE) && (st.L == SB) && (st.L2 == SB) && (n - (st.r0 + 2 * SB) >= SB) && (sw + 1 < n - 2);
+    if (fast) body_v7A<PAR, 1, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, st, dg, xpre, Bc, Dc, Bn, Dn, act);
+    else body_v7A<PAR, 0, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, st, dg, xpre, Bc, Dc, Bn, Dn, act);
+}
+
+// ---- half B: one super-step after barrier 0 (FAST: interior chase item, 64 x 64 tiles) ----------
+template <int PAR, int FAST, int DIAG>
+__device__ __forceinline__ void body_v7B(double *__restrict__ AB, Sb7Shared &SH, int htid_, int ib_, int j0_,
+                                              unsigned o0_, unsigned low_, int n,
+                                              int &state, int &sw, int &done, int &stall, ChaseState &st, Diag7 &dg, int act)
 {
     constexpr int LD = 2 * SB;
     Sb7Lds &S = SH.S[1];
     const double *vc = PAR ? S.vb : S.va;
     double *vn = PAR ? S.va : S.vb;
+    // the lane constants are re-derived per super-step: kept live across the whole loop (with everything the
+    // compiler pre-computes from them: masks, row indices, LDS addresses) they do not fit the 256 registers
+    int htid = htid_, ib = ib_, j0 = j0_;
+    unsigned o0 = o0_, low = low_;
+    asm volatile("" : "+v"(htid), "+v"(ib), "+v"(j0), "+v"(o0), "+v"(low));
     const int jb = j0 >> 2;
-    SB7_STAMP(9);
-    lds_barrier();                                           // barrier 0
-    SB7_STAMP(0);
-    // item j of sweep sw needs A's items j and j+1 of sweep sw-1 (or A finished that sweep)
-    int act = ACT_IDLE;
-    if (state != 0) {
-        const int asw = SH.sweep[0], adn = SH.done[0], afin = SH.fin[0];
-        const int j = (state == 2) ? 0 : done;
-        // ... and the frame of this super-step's parity must be the one A filled with item j: true exactly two
-        // super-steps after A ran it (when A ends its sweep with item j, one step after is too early)
-        const bool ok = (afin || (asw > sw - 1) || (asw == sw - 1 && adn >= j + 2)) &&
-                        (SH.tag[PAR][0] == sw - 1 && SH.tag[PAR][1] == j);
-        if (ok) { act = (state == 2) ? ACT_ITEM0 : ACT_CHASE; stall = 0; }
-        else ++stall;
-    }
-    if ((SH.fin[0] && SH.fin[1]) || SH.abort) { state = -1; return; }
-    const bool comp = (act >= ACT_ITEM0);
-    const bool item0 = (act == ACT_ITEM0);
+    const bool comp = FAST ? true : (act >= ACT_ITEM0);
+    const bool item0 = FAST ? false : (act == ACT_ITEM0);
     const int L0 = (n - 1 - sw < SB) ? (n - 1 - sw) : SB;
     if (item0) { st.r0 = sw + 1; st.L = 0; st.L2 = L0; st.tau = 0.0; }
-    const int r0 = comp ? st.r0 : 0, L = comp ? st.L : 0, L2 = comp ? st.L2 : 0, rn = r0 + L;
+    const int r0 = comp ? st.r0 : 0, L = FAST ? SB : (comp ? st.L : 0), L2 = FAST ? SB : (comp ? st.L2 : 0), rn = r0 + L;
     const int item = item0 ? 0 : done;
     // ---- P1: this item's tiles from frame item & 1 ----
     double Bc[4][4], Dc[4][4];
@@ -1688,15 +1697,15 @@ __device__ __forceinline__ void superstep_v7B(double *__restrict__ AB, Sb7Shared
             for (int ri = 0; ri < 4; ++ri) {
                 const int i = SB3_ROW(ri), j = SB3_COL(cj);
                 // row SB-1 of B' left of its last column lies outside even the bulged band (A never writes it)
-                const bool okb = comp && (i < L2) && (j < L) && !(i == SB - 1 && j < L - 1);
-                const bool okd = comp && (i < L2) && (j <= i);
+                const bool okb = (FAST ? true : (comp && (i < L2) && (j < L))) && !(i == SB - 1 && j < L - 1);
+                const bool okd = (FAST ? true : (comp && (i < L2))) && (j <= i);
                 const double bv = SH.FB[f][j + 1][i + 1];
-                const double cv = SH.FB[f][SB][i + 1];
+                const double cv = FAST ? bv : SH.FB[f][SB][i + 1];      // L == SB: column L-1 reads FB[f][SB][.] anyway
                 const double dv = fd_ref<f>(SH, i + 1, j + 1);
-                Bc[ri][cj] = okb ? ((j == L - 1) ? cv : bv) : 0.0;
+                Bc[ri][cj] = okb ? ((!FAST && j == L - 1) ? cv : bv) : 0.0;
                 Dc[ri][cj] = okd ? dv : 0.0;
             }
-        if (htid < 64) { const double xv = SH.FB[f][SB][htid + 1]; xcol = (item0 && htid < L2) ? xv : 0.0; }
+        if (!FAST && htid < 64) { const double xv = SH.FB[f][SB][htid + 1]; xcol = (item0 && htid < L2) ? xv : 0.0; }
         double vcj[4];
 #pragma unroll
         for (int cj = 0; cj < 4; ++cj) vcj[cj] = vc[j0 + cj];
@@ -1723,7 +1732,7 @@ __device__ __forceinline__ void superstep_v7B(double *__restrict__ AB, Sb7Shared
         for (int q = 0; q < 16; ++q) a += S.R1[q][i];
         const double wi = item0 ? 0.0 : st.tau * a;
         const double xc = item0 ? xcol : (S.x0[i] - wi * vc[0]);
-        const double xi = (i < L2) ? xc : 0.0;
+        const double xi = (FAST || i < L2) ? xc : 0.0;
         double beta2, tau2;
         const double vi = wave_house(xi, i, L2, &beta2, &tau2);
         const double sdot = wave_sum(vi * wi);
@@ -1799,11 +1808,11 @@ __device__ __forceinline__ void superstep_v7B(double *__restrict__ AB, Sb7Shared
                 const int i = SB3_ROW(ri), j = j0 + cj;
                 double bnew = Bc[ri][cj] - (wi[ri] * vcj[cj] + vni[ri] * zj[cj]);
                 if (j == 0) bnew = (i == 0) ? beta2 : 0.0;
-                if (i < L2 && j < L) Bb[SB7_OFF(ri, cj)] = bnew;
-                if (((low >> (ri * 4 + cj)) & 1u) && i < L2)
+                if (FAST || (i < L2 && j < L)) Bb[SB7_OFF(ri, cj)] = bnew;
+                if (((low >> (ri * 4 + cj)) & 1u) && (FAST || i < L2))
                     Db[SB7_OFF(ri, cj)] = Dc[ri][cj] - (vni[ri] * pj[cj] + pi[ri] * vnj[cj]);
             }
-        if (item0 && htid < L2) AB[(size_t)sw * LD + 1 + htid] = (htid == 0) ? beta2 : 0.0;
+        if (!FAST && item0 && htid < L2) AB[(size_t)sw * LD + 1 + htid] = (htid == 0) ? beta2 : 0.0;
     }
     if (comp) {
         const bool more = (rn + L2 < n);
@@ -1823,12 +1832,39 @@ __device__ __forceinline__ void superstep_v7B(double *__restrict__ AB, Sb7Shared
     if (stall > SB7_MAX_STALL && htid == 0) { SH.abort = 1; SH.viol = 1; }
 }
 
+// ---- half B: one super-step -------------------------------------------------------------------
+template <int PAR, int DIAG>
+__device__ __forceinline__ void superstep_v7B(double *__restrict__ AB, Sb7Shared &SH, int htid, int ib, int j0,
+                                              unsigned o0, unsigned low, int n,
+                                              int &state, int &sw, int &done, int &stall, ChaseState &st, Diag7 &dg)
+{
+    SB7_STAMP(9);
+    lds_barrier();                                           // barrier 0
+    SB7_STAMP(0);
+    // item j of sweep sw needs A's items j and j+1 of sweep sw-1 (or A finished that sweep)
+    int act = ACT_IDLE;
+    if (state != 0) {
+        const int asw = SH.sweep[0], adn = SH.done[0], afin = SH.fin[0];
+        const int j = (state == 2) ? 0 : done;
+        // ... and the frame of this super-step's parity must be the one A filled with item j: true exactly two
+        // super-steps after A ran it (when A ends its sweep with item j, one step after is too early)
+        const bool ok = (afin || (asw > sw - 1) || (asw == sw - 1 && adn >= j + 2)) &&
+                        (SH.tag[PAR][0] == sw - 1 && SH.tag[PAR][1] == j);
+        if (ok) { act = (state == 2) ? ACT_ITEM0 : ACT_CHASE; stall = 0; }
+        else ++stall;
+    }
+    if ((SH.fin[0] && SH.fin[1]) || SH.abort) { state = -1; return; }
+    const bool fast = (act == ACT_CHASE) && (st.L == SB) && (st.L2 == SB);
+    if (fast) body_v7B<PAR, 1, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, stall, st, dg, act);
+    else body_v7B<PAR, 0, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, stall, st, dg, act);
+}
+
 template <int DIAG>
 __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, double *ABall, double *dall, double *eall, int *status,
                                                        long long *diag)
 {
     Diag7 dg;
-    if (DIAG) { for (int q = 0; q < 10; ++q) dg.acc[q] = 0; dg.tlast = (long long)__builtin_amdgcn_s_memtime(); }
+    if (DIAG) { for (int q = 0; q < 12; ++q) dg.acc[q] = 0; dg.tlast = (long long)__builtin_amdgcn_s_memtime(); }
     extern __shared__ __attribute__((aligned(16))) unsigned char sb7_raw[];
     Sb7Shared &SH = *reinterpret_cast<Sb7Shared *>(sb7_raw);
     constexpr int LD = 2 * SB;
@@ -1878,7 +1914,7 @@ __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, double *
         }
     }
     if (DIAG && lane == 0 && blockIdx.x == 0) {
-        for (int q = 0; q < 10; ++q) diag[(tid >> 6) * 10 + q] = dg.acc[q];
+        for (int q = 0; q < 12; ++q) diag[(tid >> 6) * 12 + q] = dg.acc[q];
     }
     __syncthreads();
     if (tid == 0 && SH.viol && status) atomicExch(status, BSP_ERR_HIP);      // exchange-frame protocol violated
@@ -1943,19 +1979,19 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
         static int diag7 = -1;
         if (diag7 < 0) { const char *e = getenv("BSP_SB2ST_DIAG"); diag7 = e ? atoi(e) : 0; }
         if (diag7) {
-            long long *dbuf = nullptr, h[80];
+            long long *dbuf = nullptr, h[96];
             BSP_HIP(hipMalloc(reinterpret_cast<void **>(&dbuf), sizeof(h)));
             hipLaunchKernelGGL(sb2st_kernel_v7<1>, dim3(batch), dim3(512), (sizeof(Sb7Shared) + 1023) / 1024 * 1024, st, n, npad,
                                d_AB, d_d, d_e, chk ? d_chk : d_status, dbuf);
             BSP_HIP(hipStreamSynchronize(st));
             BSP_HIP(hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost));
             hipFree(dbuf);
-            static const char *nm[10] = {"barrier0", "P1", "barrier1", "P2", "barrier2", "P3", "barrier3", "P4", "barrier4", "P5+upd"};
+            static const char *nm[12] = {"barrier0", "P1", "barrier1", "P2", "barrier2", "P3", "barrier3", "P4", "barrier4", "P5+upd", "vmcnt wait at P5", "-"};
             for (int wv = 0; wv < 8; ++wv) {
                 long long tot = 0;
-                for (int q = 0; q < 10; ++q) tot += h[wv * 10 + q];
+                for (int q = 0; q < 12; ++q) tot += h[wv * 12 + q];
                 fprintf(stderr, "sb2st v7 diag wave %d (Mcycles %.1f):", wv, tot / 1e6);
-                for (int q = 0; q < 10; ++q) fprintf(stderr, " [%s %.1f%%]", nm[q], 100.0 * h[wv * 10 + q] / (double)tot);
+                for (int q = 0; q < 12; ++q) fprintf(stderr, " [%s %.1f%%]", nm[q], 100.0 * h[wv * 12 + q] / (double)tot);
                 fprintf(stderr, "\n");
             }
         } else
