@@ -1414,6 +1414,7 @@ __device__ __forceinline__ double &fd_ref(Sb7Shared &SH, int i, int j)
 // diagnostic cycle stamps of v7 (DIAG instantiation only; never part of a timed or shipped run)
 struct Diag7 { long long acc[12]; long long tlast; };
 #define SB7_STAMP(k)                                                             \
+    asm volatile("; MARK stamp=%0 par=%1 fast=%2" ::"n"(k), "n"(PAR), "n"(SB7_FASTV)); \
     if (DIAG) {                                                                  \
         const long long tnow_ = (long long)__builtin_amdgcn_s_memtime();         \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       \
@@ -1423,6 +1424,7 @@ struct Diag7 { long long acc[12]; long long tlast; };
 
 // ---- half A: one super-step after barrier 0.  FAST: an interior chase item (64 x 64 tiles, a full successor,
 // a partner sweep) -- every range mask is true and folds away; the general instantiation handles the rest.
+#define SB7_FASTV FAST
 template <int PAR, int FAST, int DIAG>
 __device__ __forceinline__ void body_v7A(double *__restrict__ AB, Sb7Shared &SH, int htid_, int ib_, int j0_,
                                               unsigned o0_, unsigned low_, int n,
@@ -1443,7 +1445,11 @@ __device__ __forceinline__ void body_v7A(double *__restrict__ AB, Sb7Shared &SH,
     const bool item0 = FAST ? false : (act == ACT_ITEM0);
     const int L0 = (n - 1 - sw < SB) ? (n - 1 - sw) : SB;
     if (item0) { st.r0 = sw + 1; st.L = 0; st.L2 = L0; st.tau = 0.0; }
-    const int r0 = comp ? st.r0 : 0, L = FAST ? SB : (comp ? st.L : 0), L2 = FAST ? SB : (comp ? st.L2 : 0), rn = r0 + L;
+    // wave-uniform by construction; telling the compiler so keeps the tile bases in SGPRs (scalar base + lane offset
+    // + immediate addressing for all 32 loads)
+    const int r0 = __builtin_amdgcn_readfirstlane(comp ? st.r0 : 0);
+    const int L = FAST ? SB : __builtin_amdgcn_readfirstlane(comp ? st.L : 0);
+    const int L2 = FAST ? SB : __builtin_amdgcn_readfirstlane(comp ? st.L2 : 0), rn = r0 + L;
     int pr0, pL, pL2;
     bool have_pf;
     if (FAST) { pr0 = rn; pL = SB; pL2 = SB; have_pf = true; }
@@ -1456,18 +1462,32 @@ __device__ __forceinline__ void body_v7A(double *__restrict__ AB, Sb7Shared &SH,
     {
         const double *__restrict__ Bb = have_pf ? (AB + ((size_t)pr0 * LD + pL)) : AB;
         const double *__restrict__ Db = have_pf ? (AB + (size_t)(pr0 + pL) * LD) : AB;
+        if (FAST) {
+            // one lane pointer per tile + compile-time offsets: no address arithmetic per load.  Every address is
+            // valid (an upper-triangle D entry reads the tail of the previous column and is masked afterwards).
+            const double *__restrict__ Bl = Bb + o0, *__restrict__ Dl = Db + o0;
 #pragma unroll
-        for (int cj = 0; cj < 4; ++cj)
+            for (int cj = 0; cj < 4; ++cj)
 #pragma unroll
-            for (int ri = 0; ri < 4; ++ri) {
-                const int i = SB3_ROW(ri), j = SB3_COL(cj);
-                const bool okb = FAST ? true : (have_pf && (i < pL2) && (j < pL));
-                const bool okd = ((low >> (ri * 4 + cj)) & 1u) && (FAST ? true : (have_pf && (i < pL2)));
-                const double bv = Bb[okb ? SB7_OFF(ri, cj) : 0u];
-                const double dv = Db[okd ? SB7_OFF(ri, cj) : 0u];
-                Bn[ri][cj] = okb ? bv : 0.0;
-                Dn[ri][cj] = okd ? dv : 0.0;
-            }
+                for (int ri = 0; ri < 4; ++ri) {
+                    Bn[ri][cj] = Bl[cj * (LD - 1) + 16 * ri];
+                    const double dv = Dl[cj * (LD - 1) + 16 * ri];
+                    Dn[ri][cj] = ((low >> (ri * 4 + cj)) & 1u) ? dv : 0.0;
+                }
+        } else {
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri) {
+                    const int i = SB3_ROW(ri), j = SB3_COL(cj);
+                    const bool okb = have_pf && (i < pL2) && (j < pL);
+                    const bool okd = have_pf && ((low >> (ri * 4 + cj)) & 1u) && (i < pL2);
+                    const double bv = Bb[okb ? SB7_OFF(ri, cj) : 0u];
+                    const double dv = Db[okd ? SB7_OFF(ri, cj) : 0u];
+                    Bn[ri][cj] = okb ? bv : 0.0;
+                    Dn[ri][cj] = okd ? dv : 0.0;
+                }
+        }
         if (!FAST) {                                          // every wave loads (a branch around a load drains vmcnt)
             const bool okx = (act == ACT_PRELOAD) && (htid < L0);
             const double xr = AB[okx ? ((size_t)sw * LD + 1 + htid) : 0];
@@ -1589,7 +1609,11 @@ __device__ __forceinline__ void body_v7A(double *__restrict__ AB, Sb7Shared &SH,
                         }
                         // the annihilated column is outside every tile of sweep s+1 but inside item k-1's tile of
                         // sweep s+2, and HBM still holds sweep s-1's bulge there: the zeros must land
-                        if (cj == 0 && jb == 0 && i >= 1 && inb) Bb[SB7_OFF(ri, 0)] = 0.0;
+                        if (cj == 0 && jb == 0 && i >= 1 && inb) {
+                            double zero;                      // materialised here: kept in a register across the loop
+                            asm volatile("v_mov_b64 %0, 0" : "=v"(zero));   // the constant gets spilled and reloaded
+                            Bb[SB7_OFF(ri, 0)] = zero;        // behind an s_waitcnt vmcnt(0), i.e. behind the prefetch
+                        }
                     } else if (inb) Bb[SB7_OFF(ri, cj)] = bnew;
                 }
         }
@@ -1635,6 +1659,8 @@ __device__ __forceinline__ void body_v7A(double *__restrict__ AB, Sb7Shared &SH,
     }
 }
 
+#undef SB7_FASTV
+#define SB7_FASTV (-1)
 // ---- half A: one super-step -------------------------------------------------------------------
 template <int PAR, int DIAG>
 __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared &SH, int htid, int ib, int j0,
@@ -1647,7 +1673,7 @@ __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared
     SB7_STAMP(0);
     int act = ACT_IDLE;
     {
-        const int osw = SH.sweep[1], odn = SH.done[1], ofin = SH.fin[1];
+        const int osw = __builtin_amdgcn_readfirstlane(SH.sweep[1]), odn = __builtin_amdgcn_readfirstlane(SH.done[1]), ofin = __builtin_amdgcn_readfirstlane(SH.fin[1]);
         if (state == 1) {
             // B must be (a) SB7_LAG_HBM items into sweep sw-1, so that the tiles this sweep loads are in HBM, and
             // (b) at most one item from its end: item 0 of this sweep (next super-step) overwrites frame 0
@@ -1658,12 +1684,14 @@ __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared
         } else if (state == 2) act = ACT_ITEM0;
         else if (state == 3) act = ACT_CHASE;
     }
-    if ((SH.fin[0] && SH.fin[1]) || SH.abort) { state = -1; return; }
+    if (__builtin_amdgcn_readfirstlane((SH.fin[0] && SH.fin[1]) || SH.abort)) { state = -1; return; }
     const bool fast = (act == ACT_CHASE) && (st.L == SB) && (st.L2 == SB) && (n - (st.r0 + 2 * SB) >= SB) && (sw + 1 < n - 2);
     if (fast) body_v7A<PAR, 1, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, st, dg, xpre, Bc, Dc, Bn, Dn, act);
     else body_v7A<PAR, 0, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, st, dg, xpre, Bc, Dc, Bn, Dn, act);
 }
 
+#undef SB7_FASTV
+#define SB7_FASTV FAST
 // ---- half B: one super-step after barrier 0 (FAST: interior chase item, 64 x 64 tiles) ----------
 template <int PAR, int FAST, int DIAG>
 __device__ __forceinline__ void body_v7B(double *__restrict__ AB, Sb7Shared &SH, int htid_, int ib_, int j0_,
@@ -1684,7 +1712,9 @@ __device__ __forceinline__ void body_v7B(double *__restrict__ AB, Sb7Shared &SH,
     const bool item0 = FAST ? false : (act == ACT_ITEM0);
     const int L0 = (n - 1 - sw < SB) ? (n - 1 - sw) : SB;
     if (item0) { st.r0 = sw + 1; st.L = 0; st.L2 = L0; st.tau = 0.0; }
-    const int r0 = comp ? st.r0 : 0, L = FAST ? SB : (comp ? st.L : 0), L2 = FAST ? SB : (comp ? st.L2 : 0), rn = r0 + L;
+    const int r0 = __builtin_amdgcn_readfirstlane(comp ? st.r0 : 0);
+    const int L = FAST ? SB : __builtin_amdgcn_readfirstlane(comp ? st.L : 0);
+    const int L2 = FAST ? SB : __builtin_amdgcn_readfirstlane(comp ? st.L2 : 0), rn = r0 + L;
     const int item = item0 ? 0 : done;
     // ---- P1: this item's tiles from frame item & 1 ----
     double Bc[4][4], Dc[4][4];
@@ -1801,6 +1831,7 @@ __device__ __forceinline__ void body_v7B(double *__restrict__ AB, Sb7Shared &SH,
         }
         double *__restrict__ Bb = AB + ((size_t)r0 * LD + L);
         double *__restrict__ Db = AB + (size_t)rn * LD;
+        double *__restrict__ Bl = Bb + o0, *__restrict__ Dl = Db + o0;   // FAST: lane pointer + compile-time offsets
 #pragma unroll
         for (int cj = 0; cj < 4; ++cj)
 #pragma unroll
@@ -1808,9 +1839,14 @@ __device__ __forceinline__ void body_v7B(double *__restrict__ AB, Sb7Shared &SH,
                 const int i = SB3_ROW(ri), j = j0 + cj;
                 double bnew = Bc[ri][cj] - (wi[ri] * vcj[cj] + vni[ri] * zj[cj]);
                 if (j == 0) bnew = (i == 0) ? beta2 : 0.0;
-                if (FAST || (i < L2 && j < L)) Bb[SB7_OFF(ri, cj)] = bnew;
-                if (((low >> (ri * 4 + cj)) & 1u) && (FAST || i < L2))
-                    Db[SB7_OFF(ri, cj)] = Dc[ri][cj] - (vni[ri] * pj[cj] + pi[ri] * vnj[cj]);
+                const double dnew = Dc[ri][cj] - (vni[ri] * pj[cj] + pi[ri] * vnj[cj]);
+                if (FAST) {
+                    Bl[cj * (LD - 1) + 16 * ri] = bnew;
+                    if ((low >> (ri * 4 + cj)) & 1u) Dl[cj * (LD - 1) + 16 * ri] = dnew;
+                } else {
+                    if (i < L2 && j < L) Bb[SB7_OFF(ri, cj)] = bnew;
+                    if (((low >> (ri * 4 + cj)) & 1u) && i < L2) Db[SB7_OFF(ri, cj)] = dnew;
+                }
             }
         if (!FAST && item0 && htid < L2) AB[(size_t)sw * LD + 1 + htid] = (htid == 0) ? beta2 : 0.0;
     }
@@ -1832,6 +1868,8 @@ __device__ __forceinline__ void body_v7B(double *__restrict__ AB, Sb7Shared &SH,
     if (stall > SB7_MAX_STALL && htid == 0) { SH.abort = 1; SH.viol = 1; }
 }
 
+#undef SB7_FASTV
+#define SB7_FASTV (-1)
 // ---- half B: one super-step -------------------------------------------------------------------
 template <int PAR, int DIAG>
 __device__ __forceinline__ void superstep_v7B(double *__restrict__ AB, Sb7Shared &SH, int htid, int ib, int j0,
@@ -1844,16 +1882,16 @@ __device__ __forceinline__ void superstep_v7B(double *__restrict__ AB, Sb7Shared
     // item j of sweep sw needs A's items j and j+1 of sweep sw-1 (or A finished that sweep)
     int act = ACT_IDLE;
     if (state != 0) {
-        const int asw = SH.sweep[0], adn = SH.done[0], afin = SH.fin[0];
+        const int asw = __builtin_amdgcn_readfirstlane(SH.sweep[0]), adn = __builtin_amdgcn_readfirstlane(SH.done[0]), afin = __builtin_amdgcn_readfirstlane(SH.fin[0]);
         const int j = (state == 2) ? 0 : done;
         // ... and the frame of this super-step's parity must be the one A filled with item j: true exactly two
         // super-steps after A ran it (when A ends its sweep with item j, one step after is too early)
         const bool ok = (afin || (asw > sw - 1) || (asw == sw - 1 && adn >= j + 2)) &&
-                        (SH.tag[PAR][0] == sw - 1 && SH.tag[PAR][1] == j);
+                        (__builtin_amdgcn_readfirstlane(SH.tag[PAR][0]) == sw - 1 && __builtin_amdgcn_readfirstlane(SH.tag[PAR][1]) == j);
         if (ok) { act = (state == 2) ? ACT_ITEM0 : ACT_CHASE; stall = 0; }
         else ++stall;
     }
-    if ((SH.fin[0] && SH.fin[1]) || SH.abort) { state = -1; return; }
+    if (__builtin_amdgcn_readfirstlane((SH.fin[0] && SH.fin[1]) || SH.abort)) { state = -1; return; }
     const bool fast = (act == ACT_CHASE) && (st.L == SB) && (st.L2 == SB);
     if (fast) body_v7B<PAR, 1, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, stall, st, dg, act);
     else body_v7B<PAR, 0, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, stall, st, dg, act);
@@ -1868,7 +1906,7 @@ __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, double *
     extern __shared__ __attribute__((aligned(16))) unsigned char sb7_raw[];
     Sb7Shared &SH = *reinterpret_cast<Sb7Shared *>(sb7_raw);
     constexpr int LD = 2 * SB;
-    const int tid = threadIdx.x, h = tid >> 8, htid = tid & 255, lane = tid & 63, hwave = htid >> 6;
+    const int tid = threadIdx.x, h = __builtin_amdgcn_readfirstlane(tid >> 8), htid = tid & 255, lane = tid & 63, hwave = htid >> 6;
     const int ib = lane & 15, jb = (lane >> 4) + 4 * hwave;
     const int j0 = 4 * jb;
     const unsigned o0 = (unsigned)(j0 * (LD - 1) + ib);
@@ -1891,7 +1929,7 @@ __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, double *
     int sw = h, done = 0;
     ChaseState st; st.r0 = 0; st.L = 0; st.L2 = 0; st.L3 = 0; st.tau = 0.0;
     if (h == 0) {
-        int state = SH.fin[0] ? 0 : 1;
+        int state = __builtin_amdgcn_readfirstlane(SH.fin[0]) ? 0 : 1;
         double xpre = 0.0;
         double B0[4][4], D0[4][4], B1[4][4], D1[4][4];
 #pragma unroll
@@ -1905,7 +1943,7 @@ __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, double *
             if (state < 0) break;
         }
     } else {
-        int state = SH.fin[1] ? 0 : 2, stall = 0;
+        int state = __builtin_amdgcn_readfirstlane(SH.fin[1]) ? 0 : 2, stall = 0;
         for (;;) {
             superstep_v7B<0, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, stall, st, dg);
             if (state < 0) break;
