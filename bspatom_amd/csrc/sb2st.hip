@@ -1398,7 +1398,34 @@ struct Sb7Shared {
     double FD[SB + 2][TLD];         // lower triangles incl. row SB of both frames: frame 0 at FD[j][i], frame 1 at FD[i+1][j]
     int tag[2][2];                  // per frame: sweep and item of the A item that wrote its main part
     int sweep[2], done[2], fin[2], viol, abort;
+    int astate, mode;               // A's state after its last super-step (B evaluates A's cross-CU dependency too)
+    unsigned long long pw;          // partner workgroup's published progress, as last polled
 };
+
+// Two workgroups (two CUs of one XCD) per channel, as in v6: this workgroup runs sweeps first, first + 4, ...
+// (half A) and first + 1, first + 5, ... (half B); the partner runs the two sweeps in between.  Half A's
+// tiles then come from what the PARTNER's half B stored; `prog` carries B's progress across.
+struct Pair7 {
+    int paired, stride;
+    const unsigned long long *pollp;   // partner's published B progress
+    unsigned long long *pubp;          // this workgroup's
+    Sb6Ctl *C;
+    int *status;
+};
+__device__ __forceinline__ unsigned long long sb7_rfl64(unsigned long long v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+// A super-step in which a half has nothing to run: the four remaining barriers and nothing else -- no
+// side effects on the reflector buffers, the register tile sets or the exchange frames, which stay live
+// across it (half A, waiting for the partner workgroup, "holds" for an EVEN number of super-steps so that
+// the parity-indexed buffers line up again).
+__device__ __forceinline__ void sb7_idle_barriers()
+{
+    lds_barrier(); lds_barrier(); lds_barrier(); lds_barrier();
+}
 static_assert(sizeof(Sb7Shared) <= 160 * 1024, "both halves' scratch and the exchange frames must fit the CU's LDS");
 static_assert(TLD >= SB + 1, "row SB of the frames");
 
@@ -1429,7 +1456,8 @@ template <int PAR, int FAST, int DIAG>
 __device__ __forceinline__ void body_v7A(double *__restrict__ AB, Sb7Shared &SH, int htid_, int ib_, int j0_,
                                               unsigned o0_, unsigned low_, int n,
                                               int &state, int &sw, int &done, ChaseState &st, Diag7 &dg, double &xpre,
-                                              double (&Bc)[4][4], double (&Dc)[4][4], double (&Bn)[4][4], double (&Dn)[4][4], int act)
+                                              double (&Bc)[4][4], double (&Dc)[4][4], double (&Bn)[4][4], double (&Dn)[4][4], int act,
+                                              const Pair7 &pc)
 {
     constexpr int LD = 2 * SB;
     Sb7Lds &S = SH.S[0];
@@ -1459,6 +1487,13 @@ __device__ __forceinline__ void body_v7A(double *__restrict__ AB, Sb7Shared &SH,
         pr0 = rn; pL = L2; pL2 = have_pf ? ((n - (rn + L2) < SB) ? (n - (rn + L2)) : SB) : 0;
     }
     // ---- P1: prefetch from HBM (branch-free), partial w ----
+    unsigned long long pollv = 0;
+    if (pc.paired) {
+        // L1 coherence across the two CUs (as v6): a line this CU cached during its previous sweep has since been
+        // rewritten by the partner; one completed L1 invalidate before the sweep's first load removes them all
+        if (!FAST && act == ACT_PRELOAD) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        pollv = __hip_atomic_load(pc.pollp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed at the end of the step
+    }
     {
         const double *__restrict__ Bb = have_pf ? (AB + ((size_t)pr0 * LD + pL)) : AB;
         const double *__restrict__ Db = have_pf ? (AB + (size_t)(pr0 + pL) * LD) : AB;
@@ -1651,12 +1686,13 @@ __device__ __forceinline__ void body_v7A(double *__restrict__ AB, Sb7Shared &SH,
         done = item0 ? 1 : done + 1;
         if (more) state = 3;
         else {
-            sw += 2; done = 0;
+            sw += pc.stride; done = 0;
             const int Lnext = (n - 1 - sw < SB) ? (n - 1 - sw) : SB;
             state = (sw < n - 2 && Lnext >= 2) ? 1 : 0;
         }
         if (htid == 0) { SH.sweep[0] = sw; SH.done[0] = done; if (state == 0) SH.fin[0] = 1; }
     }
+    if (htid == 0) { SH.astate = state; if (pc.paired) SH.pw = pollv; }
 }
 
 #undef SB7_FASTV
@@ -1666,7 +1702,8 @@ template <int PAR, int DIAG>
 __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared &SH, int htid, int ib, int j0,
                                               unsigned o0, unsigned low, int n,
                                               int &state, int &sw, int &done, ChaseState &st, Diag7 &dg, double &xpre,
-                                              double (&Bc)[4][4], double (&Dc)[4][4], double (&Bn)[4][4], double (&Dn)[4][4])
+                                              double (&Bc)[4][4], double (&Dc)[4][4], double (&Bn)[4][4], double (&Dn)[4][4],
+                                              const Pair7 &pc)
 {
     SB7_STAMP(9);
     lds_barrier();                                           // barrier 0
@@ -1675,19 +1712,47 @@ __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared
     {
         const int osw = __builtin_amdgcn_readfirstlane(SH.sweep[1]), odn = __builtin_amdgcn_readfirstlane(SH.done[1]), ofin = __builtin_amdgcn_readfirstlane(SH.fin[1]);
         if (state == 1) {
-            // B must be (a) SB7_LAG_HBM items into sweep sw-1, so that the tiles this sweep loads are in HBM, and
-            // (b) at most one item from its end: item 0 of this sweep (next super-step) overwrites frame 0
-            const int kb = (n - sw + SB - 1) / SB;           // items of sweep sw-1
-            const int need = (kb - 2 > SB7_LAG_HBM) ? kb - 2 : SB7_LAG_HBM;
-            const bool ok = (sw == 0) || ofin || (osw > sw - 1) || (osw == sw - 1 && odn >= need);
+            // B (this workgroup's, on its previous sweep sb = sw - stride + 1) must be (a) alone: SB7_LAG_HBM items
+            // into it, so that the tiles this sweep loads are in HBM (paired: the partner's progress is checked
+            // below instead), and (b) at most one item from its end: item 0 of this sweep (next super-step)
+            // overwrites an exchange frame
+            const int sb = sw - pc.stride + 1;
+            const int kb = (n - sb - 1 + SB - 1) / SB;       // items of sweep sb
+            const int lag = pc.paired ? 0 : SB7_LAG_HBM;
+            const int need = (kb - 2 > lag) ? kb - 2 : lag;
+            bool ok = (sw < pc.stride) || ofin || (osw > sb) || (osw == sb && odn >= need);
+            if (ok && pc.paired) ok = sb6_dep_ok(sb7_rfl64(SH.pw), sw, SB6_MARGIN);   // not yet: idle and poll again
             act = ok ? ACT_PRELOAD : ACT_IDLE;
         } else if (state == 2) act = ACT_ITEM0;
         else if (state == 3) act = ACT_CHASE;
     }
     if (__builtin_amdgcn_readfirstlane((SH.fin[0] && SH.fin[1]) || SH.abort)) { state = -1; return; }
+    if (pc.paired && (state == 2 || state == 3)) {
+        // this item prefetches the next one: the partner must have published SB6_MARGIN items more of sweep sw-1
+        // (plus SB6_HYST once a wait has begun).  Otherwise half A HOLDS here for TWO super-steps at a time (an
+        // even number keeps the parity-indexed buffers, register sets and frames aligned with half B), while half B
+        // keeps running -- that is what the partner in turn waits for; blocking the whole workgroup deadlocks
+        // the pair (measured).  Nothing of A's state is touched while it holds.
+        const int need = ((state == 2) ? 1 : done + 1) + SB6_MARGIN;
+        bool waited = false;
+        for (int guard = 0; !sb6_dep_ok(sb7_rfl64(SH.pw), sw, need + (waited ? SB6_HYST : 0)); ++guard) {
+            waited = true;
+            if (htid == 0) {
+                pc.C->nwait[0] += 1;
+                if (guard > SB7_MAX_STALL) { SH.abort = 1; SH.viol = 1; }
+            }
+#pragma unroll 1
+            for (int r = 0; r < 2; ++r) {
+                if (htid == 0) SH.pw = __hip_atomic_load(pc.pollp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sb7_idle_barriers();                          // the rest of this super-step ...
+                lds_barrier();                                // ... and barrier 0 of the next
+                if (__builtin_amdgcn_readfirstlane(SH.abort)) { state = -1; return; }
+            }
+        }
+    }
     const bool fast = (act == ACT_CHASE) && (st.L == SB) && (st.L2 == SB) && (n - (st.r0 + 2 * SB) >= SB) && (sw + 1 < n - 2);
-    if (fast) body_v7A<PAR, 1, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, st, dg, xpre, Bc, Dc, Bn, Dn, act);
-    else body_v7A<PAR, 0, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, st, dg, xpre, Bc, Dc, Bn, Dn, act);
+    if (fast) body_v7A<PAR, 1, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, st, dg, xpre, Bc, Dc, Bn, Dn, act, pc);
+    else body_v7A<PAR, 0, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, st, dg, xpre, Bc, Dc, Bn, Dn, act, pc);
 }
 
 #undef SB7_FASTV
@@ -1696,7 +1761,8 @@ __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared
 template <int PAR, int FAST, int DIAG>
 __device__ __forceinline__ void body_v7B(double *__restrict__ AB, Sb7Shared &SH, int htid_, int ib_, int j0_,
                                               unsigned o0_, unsigned low_, int n,
-                                              int &state, int &sw, int &done, int &stall, ChaseState &st, Diag7 &dg, int act)
+                                              int &state, int &sw, int &done, int &stall, ChaseState &st, Diag7 &dg, int act,
+                                              const Pair7 &pc, unsigned long long &pubv, unsigned long long &pendv)
 {
     constexpr int LD = 2 * SB;
     Sb7Lds &S = SH.S[1];
@@ -1823,6 +1889,12 @@ __device__ __forceinline__ void body_v7B(double *__restrict__ AB, Sb7Shared &SH,
     lds_barrier();
     SB7_STAMP(8);
     // ---- P5: results to HBM ----
+    if (pc.paired) {
+        // the stores of the previous super-step are complete by now (the wait is free): what was pending becomes
+        // publishable, i.e. the partner learns of an item one super-step after its stores were issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pubv = pendv;
+    }
     {
         double wi[4], zj[4], vcj[4], pi[4], pj[4];
 #pragma unroll
@@ -1857,11 +1929,15 @@ __device__ __forceinline__ void body_v7B(double *__restrict__ AB, Sb7Shared &SH,
         done = item0 ? 1 : done + 1;
         if (more) state = 3;
         else {
-            sw += 2; done = 0;
+            sw += pc.stride; done = 0;
             const int Lnext = (n - 1 - sw < SB) ? (n - 1 - sw) : SB;
             state = (sw < n - 2 && Lnext >= 2) ? 2 : 0;
         }
         if (htid == 0) { SH.sweep[1] = sw; SH.done[1] = done; if (state == 0) SH.fin[1] = 1; }
+    }
+    if (pc.paired) {
+        pendv = ((unsigned long long)sw << 20) | (unsigned)done;
+        if (htid == 0) __hip_atomic_store(pc.pubp, pubv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // B missed its window (cannot happen while the halves run in lock-step): give up instead of spinning;
     // written after the last barrier, so that every wave sees it after barrier 0 of the next super-step
@@ -1874,7 +1950,8 @@ __device__ __forceinline__ void body_v7B(double *__restrict__ AB, Sb7Shared &SH,
 template <int PAR, int DIAG>
 __device__ __forceinline__ void superstep_v7B(double *__restrict__ AB, Sb7Shared &SH, int htid, int ib, int j0,
                                               unsigned o0, unsigned low, int n,
-                                              int &state, int &sw, int &done, int &stall, ChaseState &st, Diag7 &dg)
+                                              int &state, int &sw, int &done, int &stall, ChaseState &st, Diag7 &dg,
+                                              const Pair7 &pc, unsigned long long &pubv, unsigned long long &pendv)
 {
     SB7_STAMP(9);
     lds_barrier();                                           // barrier 0
@@ -1892,14 +1969,24 @@ __device__ __forceinline__ void superstep_v7B(double *__restrict__ AB, Sb7Shared
         else ++stall;
     }
     if (__builtin_amdgcn_readfirstlane((SH.fin[0] && SH.fin[1]) || SH.abort)) { state = -1; return; }
+    if (act == ACT_IDLE) {
+        if (pc.paired) {                                      // keep the progress pipeline moving (see P5)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pubv = pendv;
+            if (htid == 0) __hip_atomic_store(pc.pubp, pubv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        sb7_idle_barriers();
+        if (stall > SB7_MAX_STALL && htid == 0) { SH.abort = 1; SH.viol = 1; }
+        return;
+    }
     const bool fast = (act == ACT_CHASE) && (st.L == SB) && (st.L2 == SB);
-    if (fast) body_v7B<PAR, 1, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, stall, st, dg, act);
-    else body_v7B<PAR, 0, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, stall, st, dg, act);
+    if (fast) body_v7B<PAR, 1, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, stall, st, dg, act, pc, pubv, pendv);
+    else body_v7B<PAR, 0, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, stall, st, dg, act, pc, pubv, pendv);
 }
 
 template <int DIAG>
-__global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, double *ABall, double *dall, double *eall, int *status,
-                                                       long long *diag)
+__global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, int batch, double *ABall, double *dall, double *eall,
+                                                       int *status, long long *diag, Sb6Ctl *ctl)
 {
     Diag7 dg;
     if (DIAG) { for (int q = 0; q < 12; ++q) dg.acc[q] = 0; dg.tlast = (long long)__builtin_amdgcn_s_memtime(); }
@@ -1907,6 +1994,46 @@ __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, double *
     Sb7Shared &SH = *reinterpret_cast<Sb7Shared *>(sb7_raw);
     constexpr int LD = 2 * SB;
     const int tid = threadIdx.x, h = __builtin_amdgcn_readfirstlane(tid >> 8), htid = tid & 255, lane = tid & 63, hwave = htid >> 6;
+    // ---- which channel, alone or as one of a pair of workgroups (ctl != nullptr: v6's pairing) ----
+    int chn = blockIdx.x, w = 0;
+    Pair7 pc; pc.paired = 0; pc.stride = 2; pc.pollp = nullptr; pc.pubp = nullptr; pc.C = nullptr; pc.status = status;
+    if (ctl) {
+        // blocks b and b+8 are observed to share an XCD (round-robin dispatch): pair them, then VERIFY
+        const int blk = blockIdx.x, grp = blk >> 4, rr = blk & 15;
+        chn = grp * 8 + (rr & 7); w = rr >> 3;
+        if (chn >= batch) return;
+        Sb6Ctl *C = ctl + chn;
+        if (tid == 0) {                                       // handshake: 0 = exit, 1 = pair, 2 = alone
+            const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu;     // HW_REG_XCC_ID
+            const unsigned mine = (0x10u | xcc) << (8 * w);
+            const unsigned old = atomicOr(&C->pair, mine);
+            int mode = -1;
+            if (old & 0x80000000u) mode = 0;
+            for (int spin = 0; mode < 0 && spin < 400000; ++spin) {
+                const unsigned v = __hip_atomic_load(&C->pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v & 0x80000000u) { mode = 0; break; }
+                const unsigned ob = (v >> (8 * (w ^ 1))) & 0xffu;
+                if (ob & 0x10u) { mode = ((ob & 0xfu) == xcc) ? 1 : (w == 0 ? 2 : 0); break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (mode < 0) {                                   // partner did not show up: try to claim the channel
+                if (atomicCAS(&C->pair, mine, mine | 0x80000000u) == mine) mode = 2;
+                else {
+                    const unsigned v = __hip_atomic_load(&C->pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned ob = (v >> (8 * (w ^ 1))) & 0xffu;
+                    if (v & 0x80000000u) mode = 0;
+                    else mode = ((ob & 0x10u) && (ob & 0xfu) == xcc) ? 1 : (w == 0 ? 2 : 0);
+                }
+            }
+            SH.mode = mode;
+        }
+        __syncthreads();
+        const int mode = __builtin_amdgcn_readfirstlane(SH.mode);
+        if (mode == 0) return;
+        if (mode == 1) { pc.paired = 1; pc.stride = 4; pc.pollp = &C->prog[w ^ 1]; pc.pubp = &C->prog[w]; }
+        else w = 0;
+        pc.C = C;
+    }
     const int ib = lane & 15, jb = (lane >> 4) + 4 * hwave;
     const int j0 = 4 * jb;
     const unsigned o0 = (unsigned)(j0 * (LD - 1) + ib);
@@ -1916,17 +2043,19 @@ __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, double *
 #pragma unroll
         for (int ri = 0; ri < 4; ++ri)
             if (SB3_ROW(ri) >= j0 + cj) low |= 1u << (ri * 4 + cj);
-    const size_t ch = blockIdx.x;
+    const size_t ch = (size_t)chn;
     double *AB = ABall + ch * ab_stride(npad);
-    if (tid == 0) { SH.viol = 0; SH.abort = 0; }
+    const int first = pc.paired ? 2 * w + h : h;                 // this half's first sweep
+    if (tid == 0) { SH.viol = 0; SH.abort = 0; SH.pw = 0; }
     if (htid == 0) {
-        const int L0 = (n - 1 - h < SB) ? (n - 1 - h) : SB;
-        const bool any = (h < n - 2) && (L0 >= 2);
-        SH.sweep[h] = h; SH.done[h] = 0; SH.fin[h] = any ? 0 : 1;
+        const int L0 = (n - 1 - first < SB) ? (n - 1 - first) : SB;
+        const bool any = (first < n - 2) && (L0 >= 2);
+        SH.sweep[h] = first; SH.done[h] = 0; SH.fin[h] = any ? 0 : 1;
         SH.tag[h][0] = -1; SH.tag[h][1] = -1;
+        if (h == 0) SH.astate = any ? 1 : 0;
     }
     __syncthreads();
-    int sw = h, done = 0;
+    int sw = first, done = 0;
     ChaseState st; st.r0 = 0; st.L = 0; st.L2 = 0; st.L3 = 0; st.tau = 0.0;
     if (h == 0) {
         int state = __builtin_amdgcn_readfirstlane(SH.fin[0]) ? 0 : 1;
@@ -1937,26 +2066,49 @@ __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, double *
 #pragma unroll
             for (int c = 0; c < 4; ++c) { B0[a][c] = 0.0; D0[a][c] = 0.0; B1[a][c] = 0.0; D1[a][c] = 0.0; }
         for (;;) {
-            superstep_v7A<0, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, st, dg, xpre, B0, D0, B1, D1);
+            superstep_v7A<0, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, st, dg, xpre, B0, D0, B1, D1, pc);
             if (state < 0) break;
-            superstep_v7A<1, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, st, dg, xpre, B1, D1, B0, D0);
+            superstep_v7A<1, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, st, dg, xpre, B1, D1, B0, D0, pc);
             if (state < 0) break;
         }
     } else {
         int state = __builtin_amdgcn_readfirstlane(SH.fin[1]) ? 0 : 2, stall = 0;
+        unsigned long long pubv = (unsigned long long)sw << 20, pendv = pubv;
         for (;;) {
-            superstep_v7B<0, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, stall, st, dg);
+            superstep_v7B<0, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, stall, st, dg, pc, pubv, pendv);
             if (state < 0) break;
-            superstep_v7B<1, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, stall, st, dg);
+            superstep_v7B<1, DIAG>(AB, SH, htid, ib, j0, o0, low, n, state, sw, done, stall, st, dg, pc, pubv, pendv);
             if (state < 0) break;
         }
     }
     if (DIAG && lane == 0 && blockIdx.x == 0) {
         for (int q = 0; q < 12; ++q) diag[(tid >> 6) * 12 + q] = dg.acc[q];
     }
-    __syncthreads();
-    if (tid == 0 && SH.viol && status) atomicExch(status, BSP_ERR_HIP);      // exchange-frame protocol violated
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                          // all stores of this workgroup are complete
+    if (tid == 0 && SH.viol) {                                // exchange-frame protocol violated
+        if (status) atomicExch(status, BSP_ERR_HIP);
+        if (pc.C) atomicExch(&pc.C->err, 3 + 16 * (w + 2 * pc.paired));
+    }
     double *d = dall + ch * (size_t)npad, *e = eall + ch * (size_t)npad;
+    if (pc.paired) {
+        if (tid == 0) __hip_atomic_store(pc.pubp, SB6_FIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w != 0) return;
+        if (tid == 0) {                                       // the first workgroup writes d, e once both are done
+            int spin = 0;
+            for (; spin < 8000000; ++spin) {
+                if (__hip_atomic_load(pc.pollp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= SB6_FIN) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (spin >= 8000000) { atomicExch(&pc.C->err, 2); if (status) atomicExch(status, BSP_ERR_HIP); }
+        }
+        __syncthreads();
+        for (int j = tid; j < n; j += 512) {
+            d[j] = ld_sc1(AB + (size_t)j * LD);
+            e[j] = (j < n - 1) ? ld_sc1(AB + (size_t)j * LD + 1) : 0.0;
+        }
+        return;
+    }
     for (int j = tid; j < n; j += 512) {
         d[j] = AB[(size_t)j * LD];
         e[j] = (j < n - 1) ? AB[(size_t)j * LD + 1] : 0.0;
@@ -2001,7 +2153,8 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
             if (nerr) return BSP_ERR_HIP;
         }
     }
-    else if (ver == 7) {
+    else if (ver == 7 || ver == 8) {
+        // 7: one workgroup per channel; 8: two (the partner CU runs the two sweeps in between), v6's pairing
         static bool attr7 = false;
         if (!attr7) {
             BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sb2st_kernel_v7<0>),
@@ -2014,13 +2167,30 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
         const bool chk = getenv("BSP_SB2ST_CHECK") != nullptr;
         if (chk && !d_chk) BSP_HIP(hipMalloc(reinterpret_cast<void **>(&d_chk), sizeof(int)));
         if (chk) BSP_HIP(hipMemsetAsync(d_chk, 0, sizeof(int), st));
+        static Sb6Ctl *s_ctl7 = nullptr;
+        static int cap7 = 0;
+        Sb6Ctl *d_ctl = nullptr;
+        if (ver == 8) {
+            d_ctl = static_cast<Sb6Ctl *>(ctl);
+            if (!d_ctl) {
+                if (cap7 < batch) {
+                    if (s_ctl7) hipFree(s_ctl7);
+                    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&s_ctl7), (size_t)batch * sizeof(Sb6Ctl)));
+                    cap7 = batch;
+                }
+                d_ctl = s_ctl7;
+            }
+            BSP_HIP(hipMemsetAsync(d_ctl, 0, (size_t)batch * sizeof(Sb6Ctl), st));
+        }
+        const int nblk = (ver == 8) ? ((batch + 7) / 8) * 16 : batch;
+        const size_t lds = (sizeof(Sb7Shared) + 1023) / 1024 * 1024;
         static int diag7 = -1;
         if (diag7 < 0) { const char *e = getenv("BSP_SB2ST_DIAG"); diag7 = e ? atoi(e) : 0; }
         if (diag7) {
             long long *dbuf = nullptr, h[96];
             BSP_HIP(hipMalloc(reinterpret_cast<void **>(&dbuf), sizeof(h)));
-            hipLaunchKernelGGL(sb2st_kernel_v7<1>, dim3(batch), dim3(512), (sizeof(Sb7Shared) + 1023) / 1024 * 1024, st, n, npad,
-                               d_AB, d_d, d_e, chk ? d_chk : d_status, dbuf);
+            hipLaunchKernelGGL(sb2st_kernel_v7<1>, dim3(nblk), dim3(512), lds, st, n, npad, batch, d_AB, d_d, d_e,
+                               chk ? d_chk : d_status, dbuf, d_ctl);
             BSP_HIP(hipStreamSynchronize(st));
             BSP_HIP(hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost));
             hipFree(dbuf);
@@ -2033,13 +2203,26 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
                 fprintf(stderr, "\n");
             }
         } else
-        hipLaunchKernelGGL(sb2st_kernel_v7<0>, dim3(batch), dim3(512), (sizeof(Sb7Shared) + 1023) / 1024 * 1024, st, n, npad,
-                           d_AB, d_d, d_e, chk ? d_chk : d_status, (long long *)nullptr);
+        hipLaunchKernelGGL(sb2st_kernel_v7<0>, dim3(nblk), dim3(512), lds, st, n, npad, batch, d_AB, d_d, d_e,
+                           chk ? d_chk : d_status, (long long *)nullptr, d_ctl);
         if (chk) {
             int hv = 0;
             BSP_HIP(hipStreamSynchronize(st));
             BSP_HIP(hipMemcpy(&hv, d_chk, sizeof(int), hipMemcpyDeviceToHost));
-            if (hv) { fprintf(stderr, "bspatom: sb2st v7 exchange-slot violations (status %d)\n", hv); return BSP_ERR_HIP; }
+            if (hv) fprintf(stderr, "bspatom: sb2st v7 exchange-frame / pairing failure (status %d)\n", hv);
+            if (d_ctl) {
+                std::vector<Sb6Ctl> hc(batch);
+                BSP_HIP(hipMemcpy(hc.data(), d_ctl, (size_t)batch * sizeof(Sb6Ctl), hipMemcpyDeviceToHost));
+                int nerr = 0, nsolo = 0;
+                double nw = 0;
+                for (auto &c : hc) { nerr += c.err != 0; nsolo += (c.pair >> 31) || (((c.pair >> 8) ^ c.pair) & 0xf); nw += c.nwait[0]; }
+                fprintf(stderr, "bspatom: sb2st v8: %d channels, %d alone, %d errors, %.1f blocking waits per channel\n", batch, nsolo, nerr,
+                        nw / batch);
+                for (int c = 0, shown = 0; c < batch && shown < 8; ++c)
+                    if (hc[c].err) { fprintf(stderr, "  channel %d: err %d pair %08x prog %llx %llx\n", c, hc[c].err, hc[c].pair, hc[c].prog[0], hc[c].prog[1]); ++shown; }
+                if (nerr) return BSP_ERR_HIP;
+            }
+            if (hv) return BSP_ERR_HIP;
         }
     }
     else if (ver == 4) {
