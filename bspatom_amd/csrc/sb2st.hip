@@ -1411,6 +1411,7 @@ struct Pair7 {
     unsigned long long *pubp;          // this workgroup's
     Sb6Ctl *C;
     int *status;
+    int margin, hyst;                  // partner's published lead demanded before an item / extra once a wait began
 };
 __device__ __forceinline__ unsigned long long sb7_rfl64(unsigned long long v)
 {
@@ -1721,7 +1722,7 @@ __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared
             const int lag = pc.paired ? 0 : SB7_LAG_HBM;
             const int need = (kb - 2 > lag) ? kb - 2 : lag;
             bool ok = (sw < pc.stride) || ofin || (osw > sb) || (osw == sb && odn >= need);
-            if (ok && pc.paired) ok = sb6_dep_ok(sb7_rfl64(SH.pw), sw, SB6_MARGIN);   // not yet: idle and poll again
+            if (ok && pc.paired) ok = sb6_dep_ok(sb7_rfl64(SH.pw), sw, pc.margin);   // not yet: idle and poll again
             act = ok ? ACT_PRELOAD : ACT_IDLE;
         } else if (state == 2) act = ACT_ITEM0;
         else if (state == 3) act = ACT_CHASE;
@@ -1733,9 +1734,9 @@ __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared
         // even number keeps the parity-indexed buffers, register sets and frames aligned with half B), while half B
         // keeps running -- that is what the partner in turn waits for; blocking the whole workgroup deadlocks
         // the pair (measured).  Nothing of A's state is touched while it holds.
-        const int need = ((state == 2) ? 1 : done + 1) + SB6_MARGIN;
+        const int need = ((state == 2) ? 1 : done + 1) + pc.margin;
         bool waited = false;
-        for (int guard = 0; !sb6_dep_ok(sb7_rfl64(SH.pw), sw, need + (waited ? SB6_HYST : 0)); ++guard) {
+        for (int guard = 0; !sb6_dep_ok(sb7_rfl64(SH.pw), sw, need + (waited ? pc.hyst : 0)); ++guard) {
             waited = true;
             if (htid == 0) {
                 pc.C->nwait[0] += 1;
@@ -1986,7 +1987,7 @@ __device__ __forceinline__ void superstep_v7B(double *__restrict__ AB, Sb7Shared
 
 template <int DIAG>
 __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, int batch, double *ABall, double *dall, double *eall,
-                                                       int *status, long long *diag, Sb6Ctl *ctl)
+                                                       int *status, long long *diag, Sb6Ctl *ctl, int margin, int hyst)
 {
     Diag7 dg;
     if (DIAG) { for (int q = 0; q < 12; ++q) dg.acc[q] = 0; dg.tlast = (long long)__builtin_amdgcn_s_memtime(); }
@@ -1997,6 +1998,7 @@ __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, int batc
     // ---- which channel, alone or as one of a pair of workgroups (ctl != nullptr: v6's pairing) ----
     int chn = blockIdx.x, w = 0;
     Pair7 pc; pc.paired = 0; pc.stride = 2; pc.pollp = nullptr; pc.pubp = nullptr; pc.C = nullptr; pc.status = status;
+    pc.margin = margin; pc.hyst = hyst;
     if (ctl) {
         // blocks b and b+8 are observed to share an XCD (round-robin dispatch): pair them, then VERIFY
         const int blk = blockIdx.x, grp = blk >> 4, rr = blk & 15;
@@ -2122,7 +2124,7 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
 {
     if (b != SB) return BSP_ERR_ARG;
     static int ver = -1;
-    if (ver < 0) { const char *e = getenv("BSP_SB2ST_VERSION"); ver = e ? atoi(e) : 6; }
+    if (ver < 0) { const char *e = getenv("BSP_SB2ST_VERSION"); ver = e ? atoi(e) : 8; }
     if (ver == 1) hipLaunchKernelGGL(sb2st_kernel, dim3(batch), dim3(256), 0, st, n, npad, d_AB, d_d, d_e);
     else if (ver == 6) {
         static Sb6Ctl *s_ctl = nullptr;
@@ -2184,13 +2186,17 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
         }
         const int nblk = (ver == 8) ? ((batch + 7) / 8) * 16 : batch;
         const size_t lds = (sizeof(Sb7Shared) + 1023) / 1024 * 1024;
-        static int diag7 = -1;
-        if (diag7 < 0) { const char *e = getenv("BSP_SB2ST_DIAG"); diag7 = e ? atoi(e) : 0; }
+        static int diag7 = -1, margin = SB6_MARGIN, hyst = 2;   // measured: 243 ms (hyst 2) .. 258 ms (hyst 16)
+        if (diag7 < 0) {
+            const char *e = getenv("BSP_SB2ST_DIAG"); diag7 = e ? atoi(e) : 0;
+            if ((e = getenv("BSP_SB2ST_MARGIN"))) margin = atoi(e);
+            if ((e = getenv("BSP_SB2ST_HYST"))) hyst = atoi(e);
+        }
         if (diag7) {
             long long *dbuf = nullptr, h[96];
             BSP_HIP(hipMalloc(reinterpret_cast<void **>(&dbuf), sizeof(h)));
             hipLaunchKernelGGL(sb2st_kernel_v7<1>, dim3(nblk), dim3(512), lds, st, n, npad, batch, d_AB, d_d, d_e,
-                               chk ? d_chk : d_status, dbuf, d_ctl);
+                               chk ? d_chk : d_status, dbuf, d_ctl, margin, hyst);
             BSP_HIP(hipStreamSynchronize(st));
             BSP_HIP(hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost));
             hipFree(dbuf);
@@ -2204,7 +2210,7 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
             }
         } else
         hipLaunchKernelGGL(sb2st_kernel_v7<0>, dim3(nblk), dim3(512), lds, st, n, npad, batch, d_AB, d_d, d_e,
-                           chk ? d_chk : d_status, (long long *)nullptr, d_ctl);
+                           chk ? d_chk : d_status, (long long *)nullptr, d_ctl, margin, hyst);
         if (chk) {
             int hv = 0;
             BSP_HIP(hipStreamSynchronize(st));
