@@ -1738,14 +1738,15 @@ __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared
         bool waited = false;
         for (int guard = 0; !sb6_dep_ok(sb7_rfl64(SH.pw), sw, need + (waited ? pc.hyst : 0)); ++guard) {
             waited = true;
-            if (htid == 0) {
-                pc.C->nwait[0] += 1;
-                if (guard > SB7_MAX_STALL) { SH.abort = 1; SH.viol = 1; }
-            }
 #pragma unroll 1
             for (int r = 0; r < 2; ++r) {
-                if (htid == 0) SH.pw = __hip_atomic_load(pc.pollp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sb7_idle_barriers();                          // the rest of this super-step ...
+                lds_barrier();                                // every wave has evaluated the condition above: only
+                if (htid == 0) {                              // now may the shared words it read change
+                    SH.pw = __hip_atomic_load(pc.pollp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (r == 0) pc.C->nwait[0] += 1;
+                    if (guard > SB7_MAX_STALL) { SH.abort = 1; SH.viol = 1; }
+                }
+                lds_barrier(); lds_barrier(); lds_barrier();  // the rest of this super-step ...
                 lds_barrier();                                // ... and barrier 0 of the next
                 if (__builtin_amdgcn_readfirstlane(SH.abort)) { state = -1; return; }
             }
@@ -1936,10 +1937,7 @@ __device__ __forceinline__ void body_v7B(double *__restrict__ AB, Sb7Shared &SH,
         }
         if (htid == 0) { SH.sweep[1] = sw; SH.done[1] = done; if (state == 0) SH.fin[1] = 1; }
     }
-    if (pc.paired) {
-        pendv = ((unsigned long long)sw << 20) | (unsigned)done;
-        if (htid == 0) __hip_atomic_store(pc.pubp, pubv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (pc.paired) pendv = ((unsigned long long)sw << 20) | (unsigned)done;
     // B missed its window (cannot happen while the halves run in lock-step): give up instead of spinning;
     // written after the last barrier, so that every wave sees it after barrier 0 of the next super-step
     if (stall > SB7_MAX_STALL && htid == 0) { SH.abort = 1; SH.viol = 1; }
@@ -1957,6 +1955,9 @@ __device__ __forceinline__ void superstep_v7B(double *__restrict__ AB, Sb7Shared
     SB7_STAMP(9);
     lds_barrier();                                           // barrier 0
     SB7_STAMP(0);
+    // publish what became publishable in the previous super-step: EVERY wave of this half has since passed its
+    // s_waitcnt vmcnt(0) (and this barrier), so all stores of the items counted in pubv are complete
+    if (pc.paired && htid == 0) __hip_atomic_store(pc.pubp, pubv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // item j of sweep sw needs A's items j and j+1 of sweep sw-1 (or A finished that sweep)
     int act = ACT_IDLE;
     if (state != 0) {
@@ -1974,7 +1975,6 @@ __device__ __forceinline__ void superstep_v7B(double *__restrict__ AB, Sb7Shared
         if (pc.paired) {                                      // keep the progress pipeline moving (see P5)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             pubv = pendv;
-            if (htid == 0) __hip_atomic_store(pc.pubp, pubv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         sb7_idle_barriers();
         if (stall > SB7_MAX_STALL && htid == 0) { SH.abort = 1; SH.viol = 1; }

@@ -236,6 +236,18 @@ def test_full_size_properties_128_channels():
     prob.close()
 
 
+def test_full_size_batch_is_deterministic():
+    """The paired bulge-chasing workgroups synchronise through published progress words; the arithmetic and its
+    order do not depend on their timing, so repeated solves must agree bit for bit (a race shows up as a difference)."""
+    prob = capi.Problem(input_from_case("c4_4096", l_fin=127))
+    E0, info = prob.solve(0, 128)
+    assert np.all(info == 0)
+    for _ in range(3):
+        E, info = prob.solve(0, 128)
+        assert np.array_equal(E, E0)
+    prob.close()
+
+
 def test_invalid_requests():
     prob = capi.Problem(input_from_case("c1_lin"))
     with pytest.raises(capi.BspAtomError):
