@@ -16,6 +16,26 @@
 
 namespace bsp {
 
+// One k-step (depth 4) of a (16 TM) x (16 TN) wave tile: acc[i][j] += A(16 rows of block i, 4) * B(4, 16 cols of block j).
+// Arow / Brow: LDS row k0 + (lane >> 4) of this wave's A / B tile.  (A core on v_mfma_f64_4x4x4, whose layouts nest in
+// these -- tools/microbench/mfma4_probe.hip -- and which a register-only loop runs at 72 TFLOP/s against 36-48 for
+// 16x16x4 -- tools/microbench/mfma_f64_peak.hip -- was tried: 20 instead of 8 LDS reads per step, and the kernels
+// came out 2-5 % SLOWER; they are not bound by the matrix pipe.)
+template <int TM, int TN>
+__device__ __forceinline__ void mfma_step(const double *Arow, const double *Brow, int lane, double4_t (&acc)[TM][TN])
+{
+    double a[TM], b[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[i] = Arow[i * 16 + (lane & 15)];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[j] = Brow[j * 16 + (lane & 15)];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+}
+
+
 constexpr int BK = 16;
 
 template <int BM, int BN, int WM, int WN, int ALAY, int BLAY>
@@ -96,16 +116,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc g)
 #pragma unroll
         for (int k4 = 0; k4 < BK / 4; ++k4) {
             const int kr = k4 * 4 + (lane >> 4);
-            double a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[kr * LDA + wm * (BM / WM) + i * 16 + (lane & 15)];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[kr * LDB + wn * (BN / WN) + j * 16 + (lane & 15)];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            mfma_step<TM, TN>(&As[kr * LDA + wm * (BM / WM)], &Bs[kr * LDB + wn * (BN / WN)], lane, acc);
         }
         __syncthreads();
     }
@@ -302,16 +313,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmDesc g)
 #pragma unroll
         for (int k4 = 0; k4 < BK / 4; ++k4) {
             const int kr = k4 * 4 + (lane >> 4);
-            double a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[cur][kr * LDA + wm * (BM / WM) + i * 16 + (lane & 15)];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[cur][kr * LDB + wn * (BN / WN) + j * 16 + (lane & 15)];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            mfma_step<TM, TN>(&As[cur][kr * LDA + wm * (BM / WM)], &Bs[cur][kr * LDB + wn * (BN / WN)], lane, acc);
         }
         if (t + 1 < nk) {
             tile_store<BM, ALAY>(ra, As[cur ^ 1], tid);
