@@ -256,12 +256,33 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmDesc g)
     __shared__ double Bs[2][BK * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int by = blockIdx.y + (MODE == 1 ? g.yoff : 0);
-    const int m0 = by * BM, n0 = blockIdx.x * BN;
-    if (MODE == 1 && by > (int)blockIdx.x + 1) return;                  // column block > row block + 1
-    const double *A = g.A + (long)blockIdx.z * g.bA;
-    const double *B = g.B + (long)blockIdx.z * g.bB;
-    double *C = g.C + (long)blockIdx.z * g.bC;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (MODE == 1) {
+        // 1-D grid over the VALID tiles only (column block by <= row block bx + 1), laid out XCD-aware: workgroups go
+        // round-robin to the 8 XCDs by linear id, so id & 7 is the XCD; XCD x takes the channels z = x, x+8, ... one
+        // after the other, row by row.  All tiles of a channel then share one L2 and its [V|Z|V] panels are fetched
+        // from HBM once instead of once per XCD (PMC: 1.8x the algorithmic bytes before).
+        const int id = blockIdx.x, xcd = id & 7, q = id >> 3;
+        const int nb = (g.N + BN - 1) / BN, T = g.lower_only;           // T: valid tiles per channel (from the launcher)
+        const int zi = q / T;
+        int t = q - zi * T;
+        bz = xcd + 8 * zi;
+        if (bz >= g.batch) return;
+        const int ylo = g.yoff, part1 = (g.yoff == 0 && T == nb);       // part 1 of the look-ahead: by == 0 only
+        bx = 0;
+        for (;;) {
+            const int yhi = part1 ? 0 : ((bx + 1 < nb - 1) ? bx + 1 : nb - 1);
+            const int c = yhi - ylo + 1;
+            if (c > 0 && t < c) break;
+            if (c > 0) t -= c;
+            ++bx;
+        }
+        by = ylo + t;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
+    const double *A = g.A + (long)bz * g.bA;
+    const double *B = g.B + (long)bz * g.bB;
+    double *C = g.C + (long)bz * g.bC;
     const double alpha = g.alpha, beta = g.beta;
 
     double2 ra[BK * BM / 512], rb[BK * BN / 512];
@@ -343,14 +364,20 @@ int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const doub
     g.A = buf + 64 * ldb; g.sAm = 1; g.sAk = ldb; g.bA = bsBuf;      // kernel-A(i'=c, k) = Q(c, k)
     g.B = buf; g.sBn = 1; g.sBk = ldb; g.bB = bsBuf;                  // kernel-B(k, j'=r) = P(r, k)
     g.C = A22; g.sCm = ld; g.sCn = 1; g.bC = bsA;                     // C'(c, r) = A22(r, c)
-    g.alpha = -1.0; g.beta = 1.0; g.lower_only = 0;
+    g.alpha = -1.0; g.beta = 1.0;
     const int nb = (m + 127) / 128;
-    int ny = nb;
-    g.yoff = 0;
-    if (part == 1) ny = 1;
-    else if (part == 2) { g.yoff = 1; ny = nb - 1; }
-    if (ny <= 0) return BSP_OK;
-    dim3 grid(nb, ny, batch);
+    // valid tiles per channel: row block bx holds column blocks ylo .. min(bx + 1, nb - 1)  (part 1: column block 0 only)
+    int T = 0;
+    g.yoff = (part == 2) ? 1 : 0;
+    if (part == 1) T = nb;
+    else
+        for (int bx = 0; bx < nb; ++bx) {
+            const int c = ((bx + 1 < nb - 1) ? bx + 1 : nb - 1) - g.yoff + 1;
+            if (c > 0) T += c;
+        }
+    if (T <= 0) return BSP_OK;
+    g.lower_only = T;                                                 // MODE 1 reads it as the tile count
+    dim3 grid((unsigned)(8 * ((batch + 7) / 8) * T), 1, 1);
     hipLaunchKernelGGL((gemm2_kernel<128, 128, 0, 0, 1>), grid, dim3(256), 0, st, g);
     BSP_HIP(hipGetLastError());
     return BSP_OK;

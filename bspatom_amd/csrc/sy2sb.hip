@@ -334,21 +334,16 @@ static int panel_and_W(int npad, int c0, int batch, double *d_A, double *buf, do
 // Look-ahead schedule: after the block column that holds the next panel has been updated (syr2k
 // part 1), QR(p+1), T and W(p+1) run on a side stream while the rest of the HBM-bound update
 // (part 2) proceeds on the main stream; the two [V|Z|V] buffers alternate between panels.
-int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipStream_t st)
+struct Sy2sbLane {                       // one pipeline: main + high-priority side stream and their events
+    hipStream_t main = nullptr, side = nullptr;
+    hipEvent_t evA = nullptr, evB = nullptr, done = nullptr;
+};
+
+static int sy2sb_pipeline(int npad, int batch, double *d_A, const Sy2sbWork &w, hipStream_t st, const Sy2sbLane &ln,
+                          int lookahead)
 {
-    if (nb != NB || npad % NB != 0) return BSP_ERR_ARG;
-    if (npad - NB > PQ_THREADS * 16) return BSP_ERR_UNSUPPORTED;   // n <= 8256
-    static hipStream_t side = nullptr;
-    static hipEvent_t evA = nullptr, evB = nullptr;
-    static int lookahead = -1;
-    if (lookahead < 0) { const char *e = getenv("BSP_SY2SB_LOOKAHEAD"); lookahead = e ? atoi(e) : 1; }
-    if (!side) {
-        int plo = 0, phi = 0;                      // the latency-bound panel work gets the high-priority queue
-        BSP_HIP(hipDeviceGetStreamPriorityRange(&plo, &phi));
-        BSP_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, phi));
-        BSP_HIP(hipEventCreateWithFlags(&evA, hipEventDisableTiming));
-        BSP_HIP(hipEventCreateWithFlags(&evB, hipEventDisableTiming));
-    }
+    hipStream_t side = ln.side;
+    hipEvent_t evA = ln.evA, evB = ln.evB;
     const long ld = npad;
     const long bsA = (long)npad * npad, bsBuf = (long)npad * 3 * NB, bsW = (long)npad * NB, bsS = NB * NB;
     const int P = npad / NB - 1;
@@ -391,6 +386,55 @@ int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipS
             if ((rc = syr2k_lower_f64(m, batch, A22, ld, bsA, buf, npad, bsBuf, 0, st))) return rc;
             if (more && (rc = panel_and_W(npad, r0, batch, d_A, bufn, taun, w, st))) return rc;
         }
+    }
+    return BSP_OK;
+}
+
+// The per-panel chain QR -> T, W -> SYMM -> K, Z -> SYR2K part 1 -> next QR is serial within a channel, and the
+// panel QR (one workgroup per channel) cannot fill the chip.  The channels are therefore split into groups that run
+// the whole pipeline independently on their own streams: while one group factors a panel the other keeps the
+// chip busy with its GEMMs.  BSP_SY2SB_GROUPS (default 2; 1 = a single pipeline on the caller's stream).
+int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipStream_t st)
+{
+    if (nb != NB || npad % NB != 0) return BSP_ERR_ARG;
+    if (npad - NB > PQ_THREADS * 16) return BSP_ERR_UNSUPPORTED;   // n <= 8256
+    constexpr int MAXG = 4;
+    static Sy2sbLane lanes[MAXG];
+    static hipEvent_t fork = nullptr;
+    static int lookahead = -1, groups = 2;
+    if (lookahead < 0) {
+        const char *e = getenv("BSP_SY2SB_LOOKAHEAD"); lookahead = e ? atoi(e) : 1;
+        if ((e = getenv("BSP_SY2SB_GROUPS"))) groups = atoi(e);
+        if (groups < 1) groups = 1;
+        if (groups > MAXG) groups = MAXG;
+        int plo = 0, phi = 0;                      // the latency-bound panel work gets the high-priority queue
+        BSP_HIP(hipDeviceGetStreamPriorityRange(&plo, &phi));
+        for (int g = 0; g < MAXG; ++g) {
+            BSP_HIP(hipStreamCreateWithFlags(&lanes[g].main, hipStreamNonBlocking));
+            BSP_HIP(hipStreamCreateWithPriority(&lanes[g].side, hipStreamNonBlocking, phi));
+            BSP_HIP(hipEventCreateWithFlags(&lanes[g].evA, hipEventDisableTiming));
+            BSP_HIP(hipEventCreateWithFlags(&lanes[g].evB, hipEventDisableTiming));
+            BSP_HIP(hipEventCreateWithFlags(&lanes[g].done, hipEventDisableTiming));
+        }
+        BSP_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    }
+    int ng = groups;
+    if (batch < 16 * ng) ng = 1;                   // small batches: one pipeline
+    if (ng == 1) return sy2sb_pipeline(npad, batch, d_A, w, st, lanes[0], lookahead);
+    BSP_HIP(hipEventRecord(fork, st));
+    const size_t bsA = (size_t)npad * npad, bsBuf = (size_t)npad * 3 * NB, bsW = (size_t)npad * NB, bsS = (size_t)NB * NB;
+    int rc = BSP_OK, c0 = 0;
+    for (int g = 0; g < ng; ++g) {
+        const int cnt = batch / ng + (g < batch % ng ? 1 : 0);
+        Sy2sbWork wg = w;
+        wg.buf = w.buf + c0 * bsBuf; wg.buf2 = w.buf2 + c0 * bsBuf; wg.W = w.W + c0 * bsW;
+        wg.G = w.G + c0 * bsS; wg.T = w.T + c0 * bsS; wg.Kmat = w.Kmat + c0 * bsS;
+        wg.tau = w.tau + (size_t)c0 * NB; wg.tau2 = w.tau2 + (size_t)c0 * NB;
+        BSP_HIP(hipStreamWaitEvent(lanes[g].main, fork, 0));
+        if ((rc = sy2sb_pipeline(npad, cnt, d_A + c0 * bsA, wg, lanes[g].main, lanes[g], lookahead))) return rc;
+        BSP_HIP(hipEventRecord(lanes[g].done, lanes[g].main));
+        BSP_HIP(hipStreamWaitEvent(st, lanes[g].done, 0));
+        c0 += cnt;
     }
     return BSP_OK;
 }
