@@ -43,8 +43,15 @@ struct GemmDesc {
     double alpha, beta;
     int lower_only;   // 1: C is square/symmetric, compute only tiles touching i >= j (col-major C)
     int yoff;         // gemm2 MODE 1: first kernel-view row block (= caller column block) of this launch
+    int ksplit;       // gemm_kernel: > 1 = split-K, grid.z = batch * ksplit, slice s covers k in [s*kchunk, (s+1)*kchunk)
+    int kchunk;       //              and writes alpha * partial to C + s*bCs (beta ignored); set by gemm_splitk_f64
+    long bCs;
 };
 int gemm_f64(const GemmDesc &g, hipStream_t st);
+// C = alpha * A B + beta * C with the K range cut into `splits` slices that run as separate workgroups (for products
+// with a small C and a long K: one tile per channel cannot fill the chip); `part` holds splits * batch * M * N
+// doubles; the slices are summed in a fixed order (deterministic).
+int gemm_splitk_f64(const GemmDesc &g, int splits, double *part, hipStream_t st);
 // pipelined, symmetry-aware products of sy2sb (see gemm_f64.hip)
 // part: 0 = all tiles, 1 = only column block 0 (look-ahead part), 2 = column blocks >= 1
 int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const double *buf, long ldb, long bsBuf,
@@ -75,7 +82,9 @@ struct Sy2sbWork {
     double *T;      // [batch][nb][nb]
     double *Kmat;   // [batch][nb][nb]
     double *tau;    // [batch][nb]
+    double *part;   // [SY2SB_SPLITK][batch][nb][nb] split-K partial sums of G and K
 };
+constexpr int SY2SB_SPLITK = 16;
 size_t sy2sb_work_bytes(int npad, int nb, int batch);
 void sy2sb_carve(void *base, int npad, int nb, int batch, Sy2sbWork *w);
 int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipStream_t st);

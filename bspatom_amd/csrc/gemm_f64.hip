@@ -52,9 +52,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc g)
     // lower_only (kernel view): 1 keeps tiles that touch i >= j, 2 keeps tiles that touch j >= i
     if (g.lower_only == 1 && m0 + BM - 1 < n0) return;
     if (g.lower_only == 2 && n0 + BN - 1 < m0) return;
-    const double *A = g.A + (long)blockIdx.z * g.bA;
-    const double *B = g.B + (long)blockIdx.z * g.bB;
-    double *C = g.C + (long)blockIdx.z * g.bC;
+    const int zb = (g.ksplit > 1) ? (int)(blockIdx.z % g.batch) : (int)blockIdx.z;
+    const int zs = (g.ksplit > 1) ? (int)(blockIdx.z / g.batch) : 0;
+    const double *A = g.A + (long)zb * g.bA;
+    const double *B = g.B + (long)zb * g.bB;
+    double *C = g.C + (long)zb * g.bC + (long)zs * g.bCs;
+    const int kbeg = (g.ksplit > 1) ? zs * g.kchunk : 0;
+    const int Kend = (g.ksplit > 1) ? ((kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K) : g.K;
 
     double4_t acc[TM][TN];
 #pragma unroll
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc g)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
+    for (int k0 = kbeg; k0 < Kend; k0 += BK) {
         // Staging loads are UNCONDITIONAL from clamped addresses, the value is selected afterwards:
         // a branch around a load makes hipcc wait vmcnt(0) per load (serialised round trips).
         // M, N are even and K is a multiple of 2 for every caller (checked in gemm_f64).
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc g)
                 const int idx = tid + it * 256;
                 const int kk = idx / (BM / 2), mm = (idx % (BM / 2)) * 2;
                 const int gm = m0 + mm, gk = k0 + kk;
-                const bool ok = (gk < g.K) && (gm + 1 < g.M);
+                const bool ok = (gk < Kend) && (gm + 1 < g.M);
                 const double2 v = *reinterpret_cast<const double2 *>(A + (ok ? ((long)gm + (long)gk * g.sAk) : 0));
                 *reinterpret_cast<double2 *>(&As[kk * LDA + mm]) = ok ? v : make_double2(0.0, 0.0);
             }
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc g)
                 const int idx = tid + it * 256;
                 const int mm = idx / (BK / 2), kk = (idx % (BK / 2)) * 2;
                 const int gm = m0 + mm, gk = k0 + kk;
-                const bool ok = (gm < g.M) && (gk + 1 < g.K);
+                const bool ok = (gm < g.M) && (gk + 1 < Kend);
                 const double2 v = *reinterpret_cast<const double2 *>(A + (ok ? ((long)gm * g.sAm + (long)gk) : 0));
                 As[kk * LDA + mm] = ok ? v.x : 0.0;
                 As[(kk + 1) * LDA + mm] = ok ? v.y : 0.0;
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc g)
                 const int idx = tid + it * 256;
                 const int kk = idx / (BN / 2), nn = (idx % (BN / 2)) * 2;
                 const int gn = n0 + nn, gk = k0 + kk;
-                const bool ok = (gk < g.K) && (gn + 1 < g.N);
+                const bool ok = (gk < Kend) && (gn + 1 < g.N);
                 const double2 v = *reinterpret_cast<const double2 *>(B + (ok ? ((long)gn + (long)gk * g.sBk) : 0));
                 *reinterpret_cast<double2 *>(&Bs[kk * LDB + nn]) = ok ? v : make_double2(0.0, 0.0);
             }
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc g)
                 const int idx = tid + it * 256;
                 const int nn = idx / (BK / 2), kk = (idx % (BK / 2)) * 2;
                 const int gn = n0 + nn, gk = k0 + kk;
-                const bool ok = (gn < g.N) && (gk + 1 < g.K);
+                const bool ok = (gn < g.N) && (gk + 1 < Kend);
                 const double2 v = *reinterpret_cast<const double2 *>(B + (ok ? ((long)gn * g.sBn + (long)gk) : 0));
                 Bs[kk * LDB + nn] = ok ? v.x : 0.0;
                 Bs[(kk + 1) * LDB + nn] = ok ? v.y : 0.0;
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc g)
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmDesc &g, int alay, int blay, hipStream_t st)
 {
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch), block(256);
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch * (g.ksplit > 1 ? g.ksplit : 1)), block(256);
     if (alay == 0 && blay == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 0, 0>), grid, block, 0, st, g);
     else if (alay == 0 && blay == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 0, 1>), grid, block, 0, st, g);
     else if (alay == 1 && blay == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1, 0>), grid, block, 0, st, g);
@@ -183,6 +187,40 @@ int gemm_f64(const GemmDesc &gin, hipStream_t st)
     return launch_cfg<64, 64, 2, 2>(g, alay, blay, st);
 }
 
+
+// sum of the split-K slices in slice order: C(i,j) = sum_s part[s][b][i*N + j] (+ beta * C)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const double *__restrict__ part, int splits, int batch, int M, int N,
+                                                           double *Call, long sCm, long sCn, long bC, double beta)
+{
+    const int b = blockIdx.y;
+    const long mn = (long)M * N;
+    for (long idx = blockIdx.x * 256 + threadIdx.x; idx < mn; idx += (long)gridDim.x * 256) {
+        double s = 0.0;
+        for (int q = 0; q < splits; ++q) s += part[((long)q * batch + b) * mn + idx];
+        const int i = (int)(idx / N), j = (int)(idx % N);
+        double *p = Call + (long)b * bC + (long)i * sCm + (long)j * sCn;
+        *p = (beta != 0.0) ? s + beta * (*p) : s;
+    }
+}
+
+int gemm_splitk_f64(const GemmDesc &gin, int splits, double *part, hipStream_t st)
+{
+    int chunk = ((gin.K + splits - 1) / splits + BK - 1) / BK * BK;
+    if (chunk < 4 * BK) chunk = 4 * BK;                               // do not split below 64-deep slices
+    const int ns = (gin.K + chunk - 1) / chunk;
+    if (ns <= 1 || !part) return gemm_f64(gin, st);
+    GemmDesc g = gin;
+    g.C = part; g.sCm = gin.N; g.sCn = 1; g.bC = (long)gin.M * gin.N; g.bCs = (long)gin.batch * gin.M * gin.N;
+    g.beta = 0.0; g.ksplit = ns; g.kchunk = chunk;
+    int rc = gemm_f64(g, st);
+    if (rc) return rc;
+    const long mn = (long)gin.M * gin.N;
+    dim3 grid((unsigned)((mn + 255) / 256 < 64 ? (mn + 255) / 256 : 64), gin.batch);
+    hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, st, part, ns, gin.batch, gin.M, gin.N, gin.C, gin.sCm, gin.sCn,
+                       gin.bC, gin.beta);
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
 
 // ================================================================================================
 // Pipelined kernels for the two big products of sy2sb (per panel):

@@ -1783,8 +1783,7 @@ __device__ __forceinline__ void body_v7B(double *__restrict__ AB, Sb7Shared &SH,
     const int r0 = __builtin_amdgcn_readfirstlane(comp ? st.r0 : 0);
     const int L = FAST ? SB : __builtin_amdgcn_readfirstlane(comp ? st.L : 0);
     const int L2 = FAST ? SB : __builtin_amdgcn_readfirstlane(comp ? st.L2 : 0), rn = r0 + L;
-    const int item = item0 ? 0 : done;
-    // ---- P1: this item's tiles from frame item & 1 ----
+    // ---- P1: this item's tiles from the frame of this super-step's parity ----
     double Bc[4][4], Dc[4][4];
     double xcol = 0.0;
     {

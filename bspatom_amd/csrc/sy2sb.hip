@@ -275,7 +275,7 @@ __global__ void extract_band_kernel(int npad, const double *__restrict__ Aall, d
 size_t sy2sb_work_bytes(int npad, int nb, int batch)
 {
     (void)nb;
-    size_t per = 2 * ((size_t)npad * 3 * NB + NB) + (size_t)npad * NB + 3 * NB * NB;
+    size_t per = 2 * ((size_t)npad * 3 * NB + NB) + (size_t)npad * NB + (3 + SY2SB_SPLITK) * NB * NB;
     return per * batch * sizeof(double);
 }
 
@@ -290,7 +290,8 @@ void sy2sb_carve(void *base, int npad, int nb, int batch, Sy2sbWork *w)
     w->T = p; p += (size_t)batch * NB * NB;
     w->Kmat = p; p += (size_t)batch * NB * NB;
     w->tau = p; p += (size_t)batch * NB;
-    w->tau2 = p;
+    w->tau2 = p; p += (size_t)batch * NB;
+    w->part = p;
 }
 
 template <int RPT>
@@ -320,7 +321,7 @@ static int panel_and_W(int npad, int c0, int batch, double *d_A, double *buf, do
     g.A = buf; g.sAm = npad; g.sAk = 1; g.bA = bsBuf;
     g.B = buf; g.sBk = 1; g.sBn = npad; g.bB = bsBuf;
     g.C = w.G; g.sCm = NB; g.sCn = 1; g.bC = bsS; g.alpha = 1.0; g.beta = 0.0;
-    if ((rc = gemm_f64(g, s))) return rc;
+    if ((rc = gemm_splitk_f64(g, SY2SB_SPLITK, w.part, s))) return rc;   // 64 x 64 x m: one tile per channel
     hipLaunchKernelGGL(form_T_kernel, dim3(batch), dim3(64), 0, s, w.G, tau, w.T);
     BSP_HIP(hipGetLastError());
     // W = V T
@@ -365,7 +366,7 @@ static int sy2sb_pipeline(int npad, int batch, double *d_A, const Sy2sbWork &w, 
         g.A = w.W; g.sAm = npad; g.sAk = 1; g.bA = bsW;
         g.B = buf + (size_t)NB * npad; g.sBk = 1; g.sBn = npad; g.bB = bsBuf;
         g.C = w.Kmat; g.sCm = 1; g.sCn = NB; g.bC = bsS; g.alpha = 1.0; g.beta = 0.0;
-        if ((rc = gemm_f64(g, st))) return rc;
+        if ((rc = gemm_splitk_f64(g, SY2SB_SPLITK, w.part, st))) return rc;
         // Z = Y - 1/2 V K  (in place)
         g.M = m; g.N = NB; g.K = NB;
         g.A = buf; g.sAm = 1; g.sAk = npad; g.bA = bsBuf;
@@ -430,6 +431,7 @@ int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipS
         wg.buf = w.buf + c0 * bsBuf; wg.buf2 = w.buf2 + c0 * bsBuf; wg.W = w.W + c0 * bsW;
         wg.G = w.G + c0 * bsS; wg.T = w.T + c0 * bsS; wg.Kmat = w.Kmat + c0 * bsS;
         wg.tau = w.tau + (size_t)c0 * NB; wg.tau2 = w.tau2 + (size_t)c0 * NB;
+        wg.part = w.part + (size_t)c0 * SY2SB_SPLITK * bsS;      // [splits][cnt][nb][nb] inside this group's share
         BSP_HIP(hipStreamWaitEvent(lanes[g].main, fork, 0));
         if ((rc = sy2sb_pipeline(npad, cnt, d_A + c0 * bsA, wg, lanes[g].main, lanes[g], lookahead))) return rc;
         BSP_HIP(hipEventRecord(lanes[g].done, lanes[g].main));
