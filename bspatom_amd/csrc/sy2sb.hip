@@ -231,6 +231,277 @@ __global__ __launch_bounds__(PQ_THREADS) void panel_qr_kernel(int npad, int r0, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// panel_qr2_kernel: the same factorisation with the memory latency taken off the chain.  Measured on the
+// kernel above: it moves ~13 KB per row of the panel (each trailing column is read twice and written once
+// per 4-column sub-panel) through ONE compute unit, with every pass waiting for its loads -- while the other
+// channel group's GEMMs saturate HBM.  Here
+//   * the trailing columns go through LDS in groups of CW2 = 2, double-buffered with LDS-DMA loads
+//     (global_load_lds_dwordx4: no VGPRs, the next group is in flight while this one is processed; both
+//     passes over a group read LDS, not memory);
+//   * the next sub-panel's four columns never leave the registers (they are the first two groups);
+//   * the wave-level half of every reduction is a DPP row scan instead of a ds_bpermute butterfly.
+// One workgroup of 512 threads per channel, rows t, t + 512, ...; RPT <= 8 (m <= 4096: two buffers of
+// 2 x 4096 doubles = 128 KB of LDS); larger panels use the kernel above.
+constexpr int CW2 = 2;
+
+template <int CTRL>
+__device__ __forceinline__ double pq_dpp(double x)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, 0xf, 0xf, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, 0xf, 0xf, true);
+    return r.d;
+}
+__device__ __forceinline__ double pq_lane(double x, int l)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_readlane(u.i[0], l);
+    r.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+    return r.d;
+}
+__device__ __forceinline__ double pq_wave_sum(double x)
+{
+    x += pq_dpp<0x111>(x); x += pq_dpp<0x112>(x); x += pq_dpp<0x114>(x); x += pq_dpp<0x118>(x);   // row_shr 1, 2, 4, 8
+    return (pq_lane(x, 15) + pq_lane(x, 31)) + (pq_lane(x, 47) + pq_lane(x, 63));
+}
+__device__ __forceinline__ void pq_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NV>
+__device__ __forceinline__ void block_allreduce2(double (&v)[NV], double *red, int lane, int wave)
+{
+    constexpr int NW = PQ_THREADS / 64;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = pq_wave_sum(v[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+    }
+    pq_barrier();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += red[w * NV + i];
+        v[i] = s;
+        // two values at a time: hoisting all NW * NV LDS reads to the front costs 2 NW NV registers and sets the
+        // kernel's register count
+        if ((i & 1) == 1) asm volatile("" : "+v"(v[i]), "+v"(v[i - 1])::"memory");
+    }
+    pq_barrier();
+}
+
+template <int RPT>
+__global__ __launch_bounds__(PQ_THREADS) void panel_qr2_kernel(int npad, int r0, int c0, double *Aall,
+                                                              double *bufall, double *tauall)
+{
+    extern __shared__ __attribute__((aligned(16))) double xs[];          // [2][CW2][MP] + 128 (sink of idle LDS-DMA)
+    constexpr int MP = PQ_THREADS * RPT;                                  // row capacity
+    __shared__ double red[(PQ_THREADS / 64) * SW * SW];
+    __shared__ double sh_alpha;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t ch = blockIdx.x;
+    const long ld = npad;
+    const int m = npad - r0;
+    double *P = Aall + ch * (size_t)npad * npad + (size_t)c0 * ld + r0;   // P(i,j) = P[i + j*ld]
+    double *buf = bufall + ch * (size_t)npad * 3 * NB;                    // buf(i,c) = buf[i + c*npad]
+    double *tau_g = tauall + ch * NB;
+    double *sink = xs + 2 * CW2 * MP;
+
+    // LDS-DMA of columns cs, cs+1 (rows 0 .. MP-1 in chunks of 128 = 1 KB per wave instruction) into buffer b.
+    // Every wave issues exactly RPT instructions per group (chunk k = wave + 8 it of CW2 * 4 RPT), so the
+    // wait below can be a literal; chunks that start beyond m are fetched from row 0 into the sink.
+    auto prefetch = [&](int cs, int b) {
+#pragma unroll
+        for (int it = 0; it < RPT; ++it) {
+            const int k = wave + (PQ_THREADS / 64) * it;                  // 0 .. CW2 * 4 * RPT - 1
+            const int c = k / (4 * RPT), rb = (k % (4 * RPT)) * 128;
+            const bool live = rb < m;
+            const int row = rb + 2 * lane;                                // m is even: a lane's pair is in or out
+            const double *src = P + (size_t)(cs + c) * ld + ((live && row < m) ? row : 0);
+            double *dst = live ? (xs + ((size_t)b * CW2 + c) * MP + rb) : sink;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+    };
+
+    // RPT <= 4: the next sub-panel (the first two groups of the trailing update) stays in registers; at RPT = 8 the
+    // second register set does not fit (spills put scratch loads, i.e. vmcnt waits, into every pass): those columns
+    // go through memory like the others and each thread re-reads the rows it wrote itself.
+    constexpr bool KEEP = (RPT <= 4);
+    double a[RPT][SW], an[KEEP ? RPT : 1][SW];
+#pragma unroll 1
+    for (int js = 0; js < NB; js += SW) {
+        const int ngroups = (NB - js - SW) / CW2;
+        if (js == 0 || !KEEP) {
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int i = tid + PQ_THREADS * q;
+#pragma unroll
+                for (int jj = 0; jj < SW; ++jj) a[q][jj] = (i < m) ? P[i + (size_t)(js + jj) * ld] : 0.0;
+            }
+        }
+        if (ngroups > 0) prefetch(js + SW, 0);            // in flight during the factorisation of the sub-panel
+        double taus[SW];
+        // ---- factor the sub-panel (registers only) ----
+#pragma unroll
+        for (int jj = 0; jj < SW; ++jj) {
+            const int j = js + jj;                       // pivot row (panel-relative)
+            double part[1] = {0.0};
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int i = tid + PQ_THREADS * q;
+                if (i > j && i < m) part[0] += a[q][jj] * a[q][jj];
+                if (i == j) sh_alpha = a[q][jj];
+            }
+            block_allreduce2<1>(part, red, lane, wave);  // barriers inside publish sh_alpha too
+            const double alpha = sh_alpha, sigma = part[0];
+            double beta, tau, scale;
+            if (j >= m - 1 || !(alpha * alpha + sigma > 1e-280) || sigma == 0.0) {
+                beta = alpha; tau = 0.0; scale = 0.0;    // nothing (numerically) below the pivot: H = I
+            } else {
+                const double nrm = sqrt(alpha * alpha + sigma);
+                beta = (alpha >= 0.0) ? -nrm : nrm;
+                tau = (beta - alpha) / beta;
+                scale = 1.0 / (alpha - beta);
+            }
+            taus[jj] = tau;
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int i = tid + PQ_THREADS * q;
+                if (i > j) a[q][jj] *= scale;            // v_i
+                if (i == j) a[q][jj] = beta;             // R(j,j)
+            }
+            if (jj < SW - 1) {                           // apply H_j to the remaining columns of the sub-panel
+                double w[SW - 1];
+#pragma unroll
+                for (int c = 0; c < SW - 1; ++c) w[c] = 0.0;
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) {
+                    const int i = tid + PQ_THREADS * q;
+                    const double vv = (i > j) ? a[q][jj] : ((i == j) ? 1.0 : 0.0);
+#pragma unroll
+                    for (int c = jj + 1; c < SW; ++c) w[c - 1] += vv * a[q][c];
+                }
+                block_allreduce2<SW - 1>(w, red, lane, wave);
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) {
+                    const int i = tid + PQ_THREADS * q;
+                    const double vv = (i > j) ? a[q][jj] : ((i == j) ? 1.0 : 0.0);
+#pragma unroll
+                    for (int c = jj + 1; c < SW; ++c) a[q][c] -= tau * vv * w[c - 1];
+                }
+            }
+        }
+        // ---- T_s of the sub-panel from G_s = V_s^T V_s (strict upper triangle: 6 values) ----
+        double g[6];                                     // (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+#pragma unroll
+        for (int x = 0; x < 6; ++x) g[x] = 0.0;
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int i = tid + PQ_THREADS * q;
+            double vv[SW];
+#pragma unroll
+            for (int c = 0; c < SW; ++c) vv[c] = (i > js + c) ? a[q][c] : ((i == js + c) ? 1.0 : 0.0);
+            g[0] += vv[0] * vv[1]; g[1] += vv[0] * vv[2]; g[2] += vv[0] * vv[3];
+            g[3] += vv[1] * vv[2]; g[4] += vv[1] * vv[3]; g[5] += vv[2] * vv[3];
+        }
+        block_allreduce2<6>(g, red, lane, wave);
+        // T (upper triangular): T(y,y) = tau_y, T(0:y, y) = -tau_y T(0:y,0:y) G(0:y, y)
+        double Ts[SW][SW];
+#pragma unroll
+        for (int x = 0; x < SW; ++x)
+#pragma unroll
+            for (int y = 0; y < SW; ++y) Ts[x][y] = 0.0;
+        Ts[0][0] = taus[0]; Ts[1][1] = taus[1]; Ts[2][2] = taus[2]; Ts[3][3] = taus[3];
+        Ts[0][1] = -taus[1] * (Ts[0][0] * g[0]);
+        Ts[0][2] = -taus[2] * (Ts[0][0] * g[1] + Ts[0][1] * g[3]);
+        Ts[1][2] = -taus[2] * (Ts[1][1] * g[3]);
+        Ts[0][3] = -taus[3] * (Ts[0][0] * g[2] + Ts[0][1] * g[4] + Ts[0][2] * g[5]);
+        Ts[1][3] = -taus[3] * (Ts[1][1] * g[4] + Ts[1][2] * g[5]);
+        Ts[2][3] = -taus[3] * (Ts[2][2] * g[5]);
+        // ---- write R / zeros back to the panel, V (explicit) to buf, tau; a becomes explicit V ----
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int i = tid + PQ_THREADS * q;
+#pragma unroll
+            for (int jj = 0; jj < SW; ++jj) {
+                const int j = js + jj;
+                const double vv = (i > j) ? a[q][jj] : ((i == j) ? 1.0 : 0.0);
+                if (i < m) {
+                    P[i + (size_t)j * ld] = (i <= j) ? a[q][jj] : 0.0;
+                    buf[i + (size_t)j * npad] = vv;
+                    buf[i + (size_t)(2 * NB + j) * npad] = vv;
+                }
+                a[q][jj] = (i < m) ? vv : 0.0;
+            }
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int jj = 0; jj < SW; ++jj) tau_g[js + jj] = taus[jj];
+        }
+        // ---- apply (I - V_s T_s^T V_s^T) to the remaining panel columns, CW2 at a time, from LDS ----
+#pragma unroll 1
+        for (int gi = 0; gi < ngroups; ++gi) {
+            const int cs = js + SW + CW2 * gi, b = gi & 1;
+            if (gi + 1 < ngroups) {
+                prefetch(cs + CW2, b ^ 1);
+                // everything this wave issued before those RPT loads -- group gi's LDS-DMA, older stores -- is done
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RPT) : "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pq_barrier();                                  // ... for every wave: buffer b is complete
+            const double *X = xs + (size_t)b * CW2 * MP;
+            double wp[SW * CW2];
+#pragma unroll
+            for (int z = 0; z < SW * CW2; ++z) wp[z] = 0.0;
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int i = tid + PQ_THREADS * q;
+#pragma unroll
+                for (int cc = 0; cc < CW2; ++cc) {
+                    const double x = (i < m) ? X[cc * MP + i] : 0.0;
+#pragma unroll
+                    for (int c = 0; c < SW; ++c) wp[c * CW2 + cc] += a[q][c] * x;
+                }
+            }
+            block_allreduce2<SW * CW2>(wp, red, lane, wave);
+            // w2 = T_s^T wp, in place (row c uses rows <= c: go down from the last)
+#pragma unroll
+            for (int c = SW - 1; c >= 0; --c)
+#pragma unroll
+                for (int cc = 0; cc < CW2; ++cc) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int z = 0; z <= c; ++z) s += Ts[z][c] * wp[z * CW2 + cc];
+                    wp[c * CW2 + cc] = s;
+                }
+            // X -= V_s w2: the first two groups are the next sub-panel and stay in registers, the rest go to memory
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int i = tid + PQ_THREADS * q;
+#pragma unroll
+                for (int cc = 0; cc < CW2; ++cc) {
+                    double x = (i < m) ? X[cc * MP + i] : 0.0;
+#pragma unroll
+                    for (int c = 0; c < SW; ++c) x -= a[q][c] * wp[c * CW2 + cc];
+                    if (KEEP && gi == 0) an[q][cc] = x;
+                    else if (KEEP && gi == 1) an[q][CW2 + cc] = x;
+                    else if (i < m) P[i + (size_t)(cs + cc) * ld] = x;
+                }
+            }
+            pq_barrier();                                  // buffer b may be overwritten by the prefetch after next
+        }
+        if (KEEP) {
+#pragma unroll
+            for (int q = 0; q < RPT; ++q)
+#pragma unroll
+                for (int jj = 0; jj < SW; ++jj) a[q][jj] = an[q][jj];
+        }
+    }
+}
+
 // T (NB x NB, upper triangular, column-major) from G = V^T V and tau: T(j,j) = tau_j,
 // T(0:j, j) = -tau_j T(0:j,0:j) G(0:j, j)   (LAPACK dlarft, forward / columnwise).
 __global__ __launch_bounds__(64) void form_T_kernel(const double *__restrict__ Gall,
@@ -297,6 +568,19 @@ void sy2sb_carve(void *base, int npad, int nb, int batch, Sy2sbWork *w)
 template <int RPT>
 static void launch_pq(int npad, int r0, int c0, int batch, double *A, double *buf, double *tau, hipStream_t st)
 {
+    static int use2 = -1;
+    if (use2 < 0) { const char *e = getenv("BSP_PANEL_QR"); use2 = e ? (atoi(e) == 2) : 1; }
+    if (use2 && RPT <= 8) {
+        const size_t lds = (size_t)(2 * CW2 * PQ_THREADS * RPT + 128) * sizeof(double);
+        static bool attr[17] = {};
+        if (!attr[RPT]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(panel_qr2_kernel<RPT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr[RPT] = true;
+        }
+        hipLaunchKernelGGL((panel_qr2_kernel<RPT>), dim3(batch), dim3(PQ_THREADS), lds, st, npad, r0, c0, A, buf, tau);
+        return;
+    }
     hipLaunchKernelGGL((panel_qr_kernel<RPT>), dim3(batch), dim3(PQ_THREADS), 0, st, npad, r0, c0, A, buf, tau);
 }
 
