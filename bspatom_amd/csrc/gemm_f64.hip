@@ -239,6 +239,9 @@ int gemm_splitk_f64(const GemmDesc &gin, int splits, double *part, hipStream_t s
 // first tiles are staged, so the epilogue is a pure store.
 // ================================================================================================
 __device__ __forceinline__ void lds_barrier2() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// timing experiments only (BSP_GEMM_DIAG): cycle stamps of one workgroup's phases, summed over its life
+__device__ long long g_gemm2_diag[8];
+#define G2_STAMP(k) if (DIAGG) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dacc[k] += t_ - tl; tl = t_; }
 
 // tile staging: element (x, k) of an X-by-K operand; LAY 0: contiguous along x, stride sk along k;
 // LAY 1: contiguous along k, stride sx along x.  NR = double2 registers per thread.
@@ -284,9 +287,11 @@ __device__ __forceinline__ void tile_store(const double2 (&r)[BK * BX / 512], do
 }
 
 // kernel view: C'(i', j') with j' memory-contiguous (sCn == 1 required).
-template <int BM, int BN, int ALAY, int BLAY, int MODE>
+template <int BM, int BN, int ALAY, int BLAY, int MODE, int DIAGG = 0>
 __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmDesc g)
 {
+    long long dacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tl = DIAGG ? (long long)__builtin_amdgcn_s_memtime() : 0;
     constexpr int WM = 2, WN = 2;
     constexpr int LDA = BM + 16, LDB = BN + 16;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -358,9 +363,12 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmDesc g)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
     }
+    G2_STAMP(0)                                              // C, first A/B tiles: loads issued
+    if (DIAGG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); G2_STAMP(1) }   // ... and arrived
     tile_store<BM, ALAY>(ra, As[0], tid);
     storeB(0, Bs[0]);
     lds_barrier2();
+    G2_STAMP(2)
 
     const int nk = (g.K + BK - 1) / BK;
     for (int t = 0; t < nk; ++t) {
@@ -374,11 +382,14 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmDesc g)
             const int kr = k4 * 4 + (lane >> 4);
             mfma_step<TM, TN>(&As[cur][kr * LDA + wm * (BM / WM)], &Bs[cur][kr * LDB + wn * (BN / WN)], lane, acc);
         }
+        G2_STAMP(3)                                          // MFMAs of this k-tile (and issue of the next loads)
         if (t + 1 < nk) {
+            if (DIAGG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); G2_STAMP(4) }   // wait for the next tile
             tile_store<BM, ALAY>(ra, As[cur ^ 1], tid);
             storeB((t + 1) * BK, Bs[cur ^ 1]);
         }
         lds_barrier2();
+        G2_STAMP(5)
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -390,6 +401,12 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmDesc g)
                 const int gj = n0 + wn * (BN / WN) + j * 16 + (lane & 15);
                 if (gi < g.M && gj < g.N) C[(long)gi * g.sCm + (long)gj] = alpha * acc[i][j][r];
             }
+    G2_STAMP(6)
+    if (DIAGG) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        G2_STAMP(7)
+        if (tid == 0) for (int q = 0; q < 8; ++q) atomicAdd((unsigned long long *)&g_gemm2_diag[q], (unsigned long long)dacc[q]);
+    }
 }
 
 // A22 (m x m, column-major, ld) -= P Q^T with P = buf[:, 0:128], Q = buf[:, 64:192] (ldb rows apart),
@@ -416,6 +433,22 @@ int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const doub
     if (T <= 0) return BSP_OK;
     g.lower_only = T;                                                 // MODE 1 reads it as the tile count
     dim3 grid((unsigned)(8 * ((batch + 7) / 8) * T), 1, 1);
+    static int gd = -1;
+    if (gd < 0) { const char *e = getenv("BSP_GEMM_DIAG"); gd = e ? atoi(e) : 0; }
+    if (gd && part == 2 && m >= 3900) {
+        long long z[8] = {0};
+        BSP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm2_diag), z, sizeof(z)));
+        hipLaunchKernelGGL((gemm2_kernel<128, 128, 0, 0, 1, 1>), grid, dim3(256), 0, st, g);
+        BSP_HIP(hipStreamSynchronize(st));
+        BSP_HIP(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_gemm2_diag), sizeof(z)));
+        static const char *nm[8] = {"issue C+AB0", "wait C+AB0", "LDS store+barrier", "k-tile MFMA", "wait next AB", "LDS store+barrier",
+                                    "issue C stores", "drain stores"};
+        long long tot = 0;
+        for (int q = 0; q < 8; ++q) tot += z[q];
+        fprintf(stderr, "syr2k diag (m=%d, %u workgroups, sum of wave-0 cycles %.1f M):", m, grid.x, tot / 1e6);
+        for (int q = 0; q < 8; ++q) fprintf(stderr, " [%s %.1f%%]", nm[q], 100.0 * z[q] / (double)tot);
+        fprintf(stderr, "\n");
+    } else
     hipLaunchKernelGGL((gemm2_kernel<128, 128, 0, 0, 1>), grid, dim3(256), 0, st, g);
     BSP_HIP(hipGetLastError());
     return BSP_OK;
