@@ -1501,15 +1501,14 @@ __device__ __forceinline__ void body_v7A(double *__restrict__ AB, Sb7Shared &SH,
         if (FAST) {
             // one lane pointer per tile + compile-time offsets: no address arithmetic per load.  Every address is
             // valid (an upper-triangle D entry reads the tail of the previous column and is masked afterwards).
-            const double *__restrict__ Bl = Bb + o0, *__restrict__ Dl = Db + o0;
+            // Only the B tile here; the D tile follows in P3.  A wave that issues all 32 loads at once sits in P1 until
+            // the CU's memory pipeline has taken them (measured: 30 % of the super-step), two half bursts overlap with
+            // the reductions in between.
+            const double *__restrict__ Bl = Bb + o0;
 #pragma unroll
             for (int cj = 0; cj < 4; ++cj)
 #pragma unroll
-                for (int ri = 0; ri < 4; ++ri) {
-                    Bn[ri][cj] = Bl[cj * (LD - 1) + 16 * ri];
-                    const double dv = Dl[cj * (LD - 1) + 16 * ri];
-                    Dn[ri][cj] = ((low >> (ri * 4 + cj)) & 1u) ? dv : 0.0;
-                }
+                for (int ri = 0; ri < 4; ++ri) Bn[ri][cj] = Bl[cj * (LD - 1) + 16 * ri];
         } else {
 #pragma unroll
             for (int cj = 0; cj < 4; ++cj)
@@ -1591,6 +1590,22 @@ __device__ __forceinline__ void body_v7A(double *__restrict__ AB, Sb7Shared &SH,
 #pragma unroll
             for (int ri = 0; ri < 4; ++ri) a += (SB3_ROW(ri) != j0 + cj) ? Dc[ri][cj] * vni[ri] : 0.0;
             S.R4[ib][j0 + cj] = a;
+        }
+        if (FAST) {
+            // second half of the prefetch: the D tile.  Row blocks entirely above this wave's 16 columns (ri < wave) hold
+            // no lower-triangle entry: not loaded; the diagonal block is masked at the end of P5.
+            const double *__restrict__ Dl = AB + (size_t)(pr0 + pL) * LD + o0;
+            const int hw = __builtin_amdgcn_readfirstlane(htid >> 6);
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                if (ri >= hw) {
+#pragma unroll
+                    for (int cj = 0; cj < 4; ++cj) Dn[ri][cj] = Dl[cj * (LD - 1) + 16 * ri];
+                } else {
+#pragma unroll
+                    for (int cj = 0; cj < 4; ++cj) Dn[ri][cj] = 0.0;
+                }
+            }
         }
     }
     SB7_STAMP(5);
@@ -1678,6 +1693,12 @@ __device__ __forceinline__ void body_v7A(double *__restrict__ AB, Sb7Shared &SH,
         }
         if (!FAST && item0 && htid < L2) AB[(size_t)sw * LD + 1 + htid] = (htid == 0) ? beta2 : 0.0;   // finished column s
         if (htid == 0) { SH.tag[f][0] = sw; SH.tag[f][1] = item; }
+        if (FAST) {                                          // the prefetched D tile has arrived: drop its upper triangle
+#pragma unroll
+            for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri) Dn[ri][cj] = ((low >> (ri * 4 + cj)) & 1u) ? Dn[ri][cj] : 0.0;
+        }
     }
     // ---- state update + publication ----
     if (!FAST && act == ACT_PRELOAD) state = 2;
