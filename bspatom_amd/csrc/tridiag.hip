@@ -125,18 +125,139 @@ __global__ __launch_bounds__(256) void bisect_kernel(int n, int ldn, const doubl
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Division-free Sturm count.  The pivot recurrence above spends most of its time in v_rcp_f64 + Newton; the
+// characteristic-polynomial form  p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}  needs a multiply, an FMA and the
+// comparison of two sign bits: count(x) = number of sign changes in p_0 = 1, p_1, ..., p_n (q_i = p_i / p_{i-1}
+// are the pivots above, so the two counts agree; an exact zero may take either sign because its successor
+// -e^2 p_{i-2} is opposite to its predecessor).  Safeguards:
+//   * the matrix is scaled by a power of two to norm <= 1 (exact), so a step changes |p| by a factor in
+//     [eps, 3]: renormalising p_i, p_{i-1} by a common power of two every 8 steps excludes over- and underflow;
+//   * e^2 is floored at 1e-60 (scaled units; moves no eigenvalue by more than 1e-30 |T|), so two successive
+//     exact zeros -- the only way the recurrence can die -- are impossible;
+//   * rows are padded to a multiple of 8 with decoupled 1 x 1 blocks d = 2 > every scaled eigenvalue.
+constexpr int RS = 8;      // steps between renormalisations
+
+__global__ __launch_bounds__(256) void bisect2_kernel(int n, int ldn, const double *__restrict__ dall,
+                                                     const double *__restrict__ eall, double *wall, long ldw)
+{
+    extern __shared__ double sm[];
+    const int np = (n + RS - 1) / RS * RS;             // padded length (steps 1 .. np, np a multiple of RS)
+    double *d = sm, *e2 = sm + np + RS;
+    __shared__ double red[8];
+    const int tid = threadIdx.x;
+    const size_t ch = blockIdx.y;
+    const double *dg = dall + ch * (size_t)ldn, *eg = eall + ch * (size_t)ldn;
+    double gl = 1e300, gu = -1e300;
+    for (int i = tid; i < n; i += 256) {
+        const double di = dg[i];
+        const double el = (i > 0) ? fabs(eg[i - 1]) : 0.0;
+        const double er = (i < n - 1) ? fabs(eg[i]) : 0.0;
+        gl = fmin(gl, di - el - er);
+        gu = fmax(gu, di + el + er);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        gl = fmin(gl, __shfl_xor(gl, off));
+        gu = fmax(gu, __shfl_xor(gu, off));
+    }
+    if ((tid & 63) == 0) { red[tid >> 6] = gl; red[4 + (tid >> 6)] = gu; }
+    __syncthreads();
+    gl = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+    gu = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+    const double eps = 2.220446049250313e-16;
+    double tnorm = fmax(fabs(gl), fabs(gu));
+    if (!(tnorm > 0.0)) tnorm = 1.0;                   // the zero matrix
+    int kexp;
+    (void)frexp(tnorm, &kexp);                         // tnorm = f 2^kexp, f in [0.5, 1)
+    const double sc = ldexp(1.0, -kexp), isc = ldexp(1.0, kexp);
+    for (int i = tid; i < np + RS; i += 256) {
+        // row i of the scaled matrix; e2[i] couples rows i and i+1.  Padding rows: d = 2, coupling at the floor.
+        d[i] = (i < n) ? dg[i] * sc : 2.0;
+        const double ev = (i < n - 1) ? (eg[i] * sc) : 0.0;
+        e2[i] = fmax(ev * ev, 1e-60);
+    }
+    __syncthreads();
+    gl = gl * sc - 2.1 * eps * n - 1e-300;             // scaled Gershgorin interval, widened as dstebz does
+    gu = gu * sc + 2.1 * eps * n + 1e-300;
+
+    const int mbase = blockIdx.x * (256 * EPT) + tid;      // eigenvalue indices mbase + 256 c
+    double lo[EPT], hi[EPT];
+#pragma unroll
+    for (int c = 0; c < EPT; ++c) { lo[c] = gl; hi[c] = gu; }
+    for (int it = 0; it < 128; ++it) {
+        double mid[EPT];
+        bool done[EPT];
+        bool alld = true;
+#pragma unroll
+        for (int c = 0; c < EPT; ++c) {
+            mid[c] = 0.5 * (lo[c] + hi[c]);
+            done[c] = (mid[c] <= lo[c]) || (mid[c] >= hi[c]) ||
+                      (hi[c] - lo[c] <= 2.0 * eps * fmax(fabs(lo[c]), fabs(hi[c])) + 1e-300);
+            alld = alld && done[c];
+        }
+        if (__syncthreads_and(alld)) break;
+        double p0[EPT], p1[EPT];
+        int cnt[EPT];
+#pragma unroll
+        for (int c = 0; c < EPT; ++c) { p0[c] = 1.0; p1[c] = d[0] - mid[c]; cnt[c] = (p1[c] < 0.0) ? 1 : 0; }
+        // rows 1 .. np-1 in blocks of RS (row 0 is done; the block that holds row 0 starts at row 1)
+        for (int ib = 0; ib < np; ib += RS) {
+#pragma unroll
+            for (int r = 0; r < RS; ++r) {
+                const int i = ib + r + 1;                  // rows 1 .. np (row np is padding too: arrays hold np + RS)
+                const double di = d[i], ei = e2[i - 1];
+#pragma unroll
+                for (int c = 0; c < EPT; ++c) {
+                    const double pn = __builtin_fma(di - mid[c], p1[c], -(ei * p0[c]));
+                    cnt[c] += (int)((unsigned)(__double2hiint(pn) ^ __double2hiint(p1[c])) >> 31);
+                    p0[c] = p1[c];
+                    p1[c] = pn;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < EPT; ++c) {
+                int ea, eb;
+                (void)frexp(p1[c], &ea);
+                (void)frexp(p0[c], &eb);
+                const int ex = (p1[c] == 0.0) ? eb : ((p0[c] == 0.0) ? ea : max(ea, eb));
+                p1[c] = ldexp(p1[c], -ex);
+                p0[c] = ldexp(p0[c], -ex);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < EPT; ++c) {
+            if (!done[c]) {
+                if (cnt[c] > mbase + 256 * c) hi[c] = mid[c]; else lo[c] = mid[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < EPT; ++c) {
+        const int m = mbase + 256 * c;
+        if (m < n) wall[ch * (size_t)ldw + m] = 0.5 * (lo[c] + hi[c]) * isc;
+    }
+}
+
 int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_e, double *d_w, long ldw,
                   hipStream_t st)
 {
-    const size_t lds = (size_t)2 * n * sizeof(double);
+    const size_t lds = (size_t)2 * (n + 3 * RS) * sizeof(double);
     if (lds > 150 * 1024) return BSP_ERR_UNSUPPORTED;
     static bool attr_set = false;
+    static int variant = 2;
     if (!attr_set) {
         BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect2_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        const char *e = getenv("BSP_BISECT");
+        if (e) variant = atoi(e);
         attr_set = true;
     }
-    hipLaunchKernelGGL(bisect_kernel, dim3((n + 256 * EPT - 1) / (256 * EPT), batch), dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
+    const dim3 grid((n + 256 * EPT - 1) / (256 * EPT), batch);
+    if (variant == 1) hipLaunchKernelGGL(bisect_kernel, grid, dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
+    else hipLaunchKernelGGL(bisect2_kernel, grid, dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }
