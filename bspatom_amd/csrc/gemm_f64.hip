@@ -322,6 +322,16 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmDesc g)
         }
         by = ylo + t;
     }
+    if (MODE == 2) {
+        // same XCD-aware layout for the SYMM-shaped product: all row tiles of a channel on one XCD, so that W (and
+        // the A22 tiles that are read a second time through the transposed address) are shared in its L2
+        const int id = blockIdx.x, xcd = id & 7, q = id >> 3;
+        const int nbx = (g.N + BN - 1) / BN;
+        const int zi = q / nbx;
+        bx = q - zi * nbx; by = 0;
+        bz = xcd + 8 * zi;
+        if (bz >= g.batch) return;
+    }
     const int m0 = by * BM, n0 = bx * BN;
     const double *A = g.A + (long)bz * g.bA;
     const double *B = g.B + (long)bz * g.bB;
@@ -464,7 +474,7 @@ int symm_lower_f64(int m, int batch, const double *A22, long ld, long bsA, const
     g.B = A22; g.sBn = 1; g.sBk = ld; g.bB = bsA;                     // kernel-B(k, j'=i) = A22(i, k) (direct part)
     g.C = Y; g.sCm = ldy; g.sCn = 1; g.bC = bsY;                      // C'(c, i) = Y(i, c)
     g.alpha = 1.0; g.beta = 0.0; g.lower_only = 0;
-    dim3 grid((m + 127) / 128, 1, batch);
+    dim3 grid((unsigned)(8 * ((batch + 7) / 8) * ((m + 127) / 128)), 1, 1);
     hipLaunchKernelGGL((gemm2_kernel<64, 128, 1, 0, 2>), grid, dim3(256), 0, st, g);
     BSP_HIP(hipGetLastError());
     return BSP_OK;

@@ -1411,7 +1411,7 @@ struct Pair7 {
     unsigned long long *pubp;          // this workgroup's
     Sb6Ctl *C;
     int *status;
-    int margin, hyst;                  // partner's published lead demanded before an item / extra once a wait began
+    int margin, hyst, lead;            // partner's published lead demanded before an item / extra once a wait began / extra at a sweep's start
 };
 __device__ __forceinline__ unsigned long long sb7_rfl64(unsigned long long v)
 {
@@ -1743,7 +1743,13 @@ __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared
             const int lag = pc.paired ? 0 : SB7_LAG_HBM;
             const int need = (kb - 2 > lag) ? kb - 2 : lag;
             bool ok = (sw < pc.stride) || ofin || (osw > sb) || (osw == sb && odn >= need);
-            if (ok && pc.paired) ok = sb6_dep_ok(sb7_rfl64(SH.pw), sw, pc.margin);   // not yet: idle and poll again
+            if (ok && pc.paired) {
+                // start a sweep with some slack behind the partner, so that timing jitter does not end in holds in
+                // mid-sweep; the slack must fit the ring (4 sweeps in flight over kb items each), hence the clamp
+                int lead = (kb - 18) / 2;
+                lead = lead < 0 ? 0 : (lead > pc.lead ? pc.lead : lead);
+                ok = sb6_dep_ok(sb7_rfl64(SH.pw), sw, pc.margin + lead);               // not yet: idle and poll again
+            }
             act = ok ? ACT_PRELOAD : ACT_IDLE;
         } else if (state == 2) act = ACT_ITEM0;
         else if (state == 3) act = ACT_CHASE;
@@ -1764,7 +1770,7 @@ __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared
                 lds_barrier();                                // every wave has evaluated the condition above: only
                 if (htid == 0) {                              // now may the shared words it read change
                     SH.pw = __hip_atomic_load(pc.pollp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (r == 0) pc.C->nwait[0] += 1;
+                    if (r == 0) { pc.C->nwait[0] += 1; if (sw * 2 < n) pc.C->nwait[1] += 1; if (state == 2) pc.C->wcycles[0] += 1; }
                     if (guard > SB7_MAX_STALL) { SH.abort = 1; SH.viol = 1; }
                 }
                 lds_barrier(); lds_barrier(); lds_barrier();  // the rest of this super-step ...
@@ -2007,7 +2013,7 @@ __device__ __forceinline__ void superstep_v7B(double *__restrict__ AB, Sb7Shared
 
 template <int DIAG>
 __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, int batch, double *ABall, double *dall, double *eall,
-                                                       int *status, long long *diag, Sb6Ctl *ctl, int margin, int hyst)
+                                                       int *status, long long *diag, Sb6Ctl *ctl, int margin, int hyst, int lead)
 {
     Diag7 dg;
     if (DIAG) { for (int q = 0; q < 12; ++q) dg.acc[q] = 0; dg.tlast = (long long)__builtin_amdgcn_s_memtime(); }
@@ -2018,7 +2024,7 @@ __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, int batc
     // ---- which channel, alone or as one of a pair of workgroups (ctl != nullptr: v6's pairing) ----
     int chn = blockIdx.x, w = 0;
     Pair7 pc; pc.paired = 0; pc.stride = 2; pc.pollp = nullptr; pc.pubp = nullptr; pc.C = nullptr; pc.status = status;
-    pc.margin = margin; pc.hyst = hyst;
+    pc.margin = margin; pc.hyst = hyst; pc.lead = lead;
     if (ctl) {
         // blocks b and b+8 are observed to share an XCD (round-robin dispatch): pair them, then VERIFY
         const int blk = blockIdx.x, grp = blk >> 4, rr = blk & 15;
@@ -2206,17 +2212,18 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
         }
         const int nblk = (ver == 8) ? ((batch + 7) / 8) * 16 : batch;
         const size_t lds = (sizeof(Sb7Shared) + 1023) / 1024 * 1024;
-        static int diag7 = -1, margin = SB6_MARGIN, hyst = 2;   // measured: 243 ms (hyst 2) .. 258 ms (hyst 16)
+        static int diag7 = -1, margin = SB6_MARGIN, lead = 16, hyst = 2;   // measured: holds 13k -> 1.6k per channel with the lead   // measured: 243 ms (hyst 2) .. 258 ms (hyst 16)
         if (diag7 < 0) {
             const char *e = getenv("BSP_SB2ST_DIAG"); diag7 = e ? atoi(e) : 0;
             if ((e = getenv("BSP_SB2ST_MARGIN"))) margin = atoi(e);
             if ((e = getenv("BSP_SB2ST_HYST"))) hyst = atoi(e);
+            if ((e = getenv("BSP_SB2ST_LEAD"))) lead = atoi(e);
         }
         if (diag7) {
             long long *dbuf = nullptr, h[96];
             BSP_HIP(hipMalloc(reinterpret_cast<void **>(&dbuf), sizeof(h)));
             hipLaunchKernelGGL(sb2st_kernel_v7<1>, dim3(nblk), dim3(512), lds, st, n, npad, batch, d_AB, d_d, d_e,
-                               chk ? d_chk : d_status, dbuf, d_ctl, margin, hyst);
+                               chk ? d_chk : d_status, dbuf, d_ctl, margin, hyst, lead);
             BSP_HIP(hipStreamSynchronize(st));
             BSP_HIP(hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost));
             hipFree(dbuf);
@@ -2230,7 +2237,7 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
             }
         } else
         hipLaunchKernelGGL(sb2st_kernel_v7<0>, dim3(nblk), dim3(512), lds, st, n, npad, batch, d_AB, d_d, d_e,
-                           chk ? d_chk : d_status, (long long *)nullptr, d_ctl, margin, hyst);
+                           chk ? d_chk : d_status, (long long *)nullptr, d_ctl, margin, hyst, lead);
         if (chk) {
             int hv = 0;
             BSP_HIP(hipStreamSynchronize(st));
@@ -2241,9 +2248,10 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
                 BSP_HIP(hipMemcpy(hc.data(), d_ctl, (size_t)batch * sizeof(Sb6Ctl), hipMemcpyDeviceToHost));
                 int nerr = 0, nsolo = 0;
                 double nw = 0;
-                for (auto &c : hc) { nerr += c.err != 0; nsolo += (c.pair >> 31) || (((c.pair >> 8) ^ c.pair) & 0xf); nw += c.nwait[0]; }
-                fprintf(stderr, "bspatom: sb2st v8: %d channels, %d alone, %d errors, %.1f blocking waits per channel\n", batch, nsolo, nerr,
-                        nw / batch);
+                double nw1 = 0, nw2 = 0;
+                for (auto &c : hc) { nerr += c.err != 0; nsolo += (c.pair >> 31) || (((c.pair >> 8) ^ c.pair) & 0xf); nw += c.nwait[0]; nw1 += c.nwait[1]; nw2 += c.wcycles[0]; }
+                fprintf(stderr, "bspatom: sb2st v8: %d channels, %d alone, %d errors, %.1f holds per channel (%.1f in the first half of the sweeps, %.1f before item 0)\n", batch, nsolo, nerr,
+                        nw / batch, nw1 / batch, nw2 / batch);
                 for (int c = 0, shown = 0; c < batch && shown < 8; ++c)
                     if (hc[c].err) { fprintf(stderr, "  channel %d: err %d pair %08x prog %llx %llx\n", c, hc[c].err, hc[c].pair, hc[c].prog[0], hc[c].prog[1]); ++shown; }
                 if (nerr) return BSP_ERR_HIP;
