@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--k", type=int, default=9)
     ap.add_argument("--rb", type=float, default=800.0)
     ap.add_argument("--channels", type=int, default=128, help="l-channels per GPU")
-    ap.add_argument("--cpu-sample-nfun", type=int, default=2048)
+    ap.add_argument("--cpu-sample-nfun", type=int, default=3072)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
