@@ -33,7 +33,7 @@ class Sizes(C.Structure):
 
 EXPORTS = ["bspatom_input_defaults", "bspatom_device_count", "bspatom_host_setup", "bspatom_problem_create", "bspatom_problem_destroy",
            "bspatom_problem_sizes", "bspatom_problem_grid", "bspatom_assemble", "bspatom_solve", "bspatom_solve_dev",
-           "bspatom_eigvec", "bspatom_write_wf", "bspatom_last_timing", "bsp_dsygv_", "bspatom_stage_gemm",
+           "bspatom_eigvec", "bspatom_eigvecs", "bspatom_write_wf", "bspatom_last_timing", "bsp_dsygv_", "bspatom_stage_gemm",
            "bspatom_stage_standard_form", "bspatom_stage_sy2sb", "bspatom_stage_sb2st", "bspatom_stage_bisect"]
 
 _lib = None
@@ -59,6 +59,7 @@ def lib():
         L.bspatom_solve.argtypes = [vp, i32, i32, vp, vp]
         L.bspatom_solve_dev.argtypes = [vp, i32, i32, vp, vp]
         L.bspatom_eigvec.argtypes = [vp, i32, i32, vp]
+        L.bspatom_eigvecs.argtypes = [vp, i32, i32, i32, vp]
         L.bspatom_write_wf.argtypes = [vp, vp, i32, vp, vp]
         L.bspatom_last_timing.argtypes = [vp, vp]
         L.bspatom_stage_gemm.argtypes = [i32, i32, i32, i32, vp, lng, lng, lng, lng, vp, lng, lng, lng, lng,
@@ -151,6 +152,12 @@ class Problem:
         c = np.zeros(self.nfun)
         _chk(lib().bspatom_eigvec(self._h, l, n0, _p(c)), "bspatom_eigvec")
         return c
+
+    def eigvecs(self, l, n0, count):
+        """Eigenvectors n0 .. n0+count-1 (1-based) of channel l: array (count, nfun), each S-normalised."""
+        Z = np.zeros((count, self.nfun))
+        _chk(lib().bspatom_eigvecs(self._h, l, n0, count, _p(Z)), "bspatom_eigvecs")
+        return Z
 
     def write_wf(self, c, npts=10000):
         c = np.ascontiguousarray(c, dtype=np.float64)

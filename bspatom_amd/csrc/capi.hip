@@ -310,6 +310,47 @@ extern "C" int bspatom_eigvec(bspatom_problem *p, int l, int n0, double *c)
     return BSP_OK;
 }
 
+struct DevBuf {
+    double *p = nullptr;
+    ~DevBuf() { hipFree(p); }
+    int alloc(size_t n) { BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p), (n ? n : 1) * sizeof(double))); return BSP_OK; }
+    int put(const double *h, size_t n) { int rc = alloc(n); if (rc) return rc; BSP_HIP(hipMemcpy(p, h, n * sizeof(double), hipMemcpyHostToDevice)); return BSP_OK; }
+    int get(double *h, size_t n) { BSP_HIP(hipMemcpy(h, p, n * sizeof(double), hipMemcpyDeviceToHost)); return BSP_OK; }
+};
+
+extern "C" int bspatom_eigvecs(bspatom_problem *p, int l, int n0, int count, double *Z)
+{
+    if (!p || !Z) return BSP_ERR_ARG;
+    const HostSetup &h = p->hs;
+    const int n = h.nfun;
+    if (l < p->last_l0 || l >= p->last_l0 + p->last_nl || n0 < 1 || count < 1 || n0 + count - 1 > n) return BSP_ERR_ARG;
+    BSP_HIP(hipSetDevice(p->device));
+    const int ch = l - p->last_l0;
+    DevBuf work, vec;
+    int rc;
+    // chunks bound the scratch: invit_work_doubles(n, k) per vector
+    const int chunk = count < 512 ? count : 512;
+    if ((rc = work.alloc((size_t)chunk * invit_work_doubles(n, h.k))) || (rc = vec.alloc((size_t)chunk * n))) return rc;
+    int *d_chan = nullptr;
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&d_chan), (size_t)chunk * sizeof(int)));
+    std::vector<int> hc(chunk, ch);
+    hipError_t e = hipMemcpy(d_chan, hc.data(), (size_t)chunk * sizeof(int), hipMemcpyHostToDevice);
+    for (int done = 0; e == hipSuccess && rc == BSP_OK && done < count; done += chunk) {
+        const int m = (count - done < chunk) ? count - done : chunk;
+        e = hipMemsetAsync(p->d_info, 0, sizeof(int), p->st);
+        if (e != hipSuccess) break;
+        rc = launch_inverse_iteration(n, h.k, m, p->d_SB, p->d_HB, d_chan, p->d_E + (size_t)ch * n + (n0 - 1 + done), work.p,
+                                      vec.p, p->d_info, p->st);
+        if (rc) break;
+        e = hipMemcpyAsync(Z + (size_t)done * n, vec.p, (size_t)m * n * sizeof(double), hipMemcpyDeviceToHost, p->st);
+        if (e == hipSuccess) e = hipStreamSynchronize(p->st);
+    }
+    hipFree(d_chan);
+    if (rc) return rc;
+    BSP_HIP(e);
+    return BSP_OK;
+}
+
 extern "C" int bspatom_write_wf(bspatom_problem *p, const double *c, int npts, double *r, double *u)
 {
     if (!p || !c || !r || !u || npts < 1) return BSP_ERR_ARG;
@@ -338,13 +379,6 @@ extern "C" int bspatom_write_wf(bspatom_problem *p, const double *c, int npts, d
 }
 
 // ---- stage-level entry points ----------------------------------------------------------------
-struct DevBuf {
-    double *p = nullptr;
-    ~DevBuf() { hipFree(p); }
-    int alloc(size_t n) { BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p), (n ? n : 1) * sizeof(double))); return BSP_OK; }
-    int put(const double *h, size_t n) { int rc = alloc(n); if (rc) return rc; BSP_HIP(hipMemcpy(p, h, n * sizeof(double), hipMemcpyHostToDevice)); return BSP_OK; }
-    int get(double *h, size_t n) { BSP_HIP(hipMemcpy(h, p, n * sizeof(double), hipMemcpyDeviceToHost)); return BSP_OK; }
-};
 
 static int need_gpu()
 {

@@ -76,3 +76,35 @@ def run(text, outdir=".", device=0, npts=10000):
     out.append("\nProgram Finished!")
     prob.close()
     return E, c, "\n".join(out)
+
+
+def write_eigenvec_all(path, prob, lmax, n1_max):
+    """`Eigenvec_All.dat` as SOLVE_SYSTEM writes it for KIND_PI >= 3 (matrices.f90:366-378): a list-directed
+    header `nfun n1_max lmax`, then per channel a list-directed `l` and n1_max records FORMAT(I5,5000G20.10)
+    `ni, c(1:nfun)`; the reader is READ_EIGENVEC (ReadInputs.f90:792-830).  The caller chooses n1_max (the
+    reference derives it from Emax_fin in its photo-ionisation branch, which is outside the hot path) and must
+    have solved channels 0..lmax."""
+    nfun = prob.nfun
+    with open(path, "w") as f:
+        f.write(" %11d %11d %11d\n" % (nfun, n1_max, lmax))            # WRITE(80,*) of three default integers
+        for l in range(lmax + 1):
+            f.write(" %11d\n" % l)
+            Z = prob.eigvecs(l, 1, n1_max)
+            for ni in range(n1_max):
+                f.write("%5d" % (ni + 1) + "".join(fortran_g(v, 20, 10) for v in Z[ni]) + "\n")
+
+
+def read_eigenvec_all(path):
+    """Reads the file back the way READ_EIGENVEC does: returns (nfun, n1_max, lmax, c[l][ni][i])."""
+    import numpy as np
+    with open(path) as f:
+        nfun, n1, lmax = (int(t) for t in f.readline().split())
+        c = np.zeros((lmax + 1, n1, nfun))
+        for l in range(lmax + 1):
+            assert int(f.readline().split()[0]) == l
+            for ni in range(n1):
+                line = f.readline()
+                assert int(line[:5]) == ni + 1
+                c[l, ni] = [float(line[5 + 20 * i: 25 + 20 * i]) for i in range(nfun)]
+    return nfun, n1, lmax, c
+

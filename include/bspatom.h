@@ -77,6 +77,12 @@ int bspatom_solve_dev(bspatom_problem *p, int l0, int nl, double *E_dev, int32_t
  * (H_l - E S), normalised c^T S c = 1; sign arbitrary (CHKPHS is commented out, :382).
  * Requires a previous bspatom_solve covering channel l.  c[nfun]. */
 int bspatom_eigvec(bspatom_problem *p, int l, int n0, double *c);
+/* The eigenvectors n0 .. n0+count-1 (1-based) of channel l, i.e. columns n0.. of DSYGV's 'V' output
+ * Hij(:, n0:n0+count-1) at matrices.f90:248 -- what the KIND_PI >= 3 branch keeps as ctemp(:,1:ntemp,l)
+ * (matrices.f90:331) and writes to Eigenvec_All.dat (:366-378, FORMAT 300 `I5,5000G20.10`): batched inverse
+ * iteration on the banded pencil, each column normalised c^T S c = 1, sign arbitrary (as LAPACK's).
+ * Z[j*nfun + i] = component i of eigenvector n0+j.  Requires a previous bspatom_solve covering l. */
+int bspatom_eigvecs(bspatom_problem *p, int l, int n0, int count, double *Z);
 
 /* WRITE_WF (Bsp_Atom.f90:118-146): u(r_i) = sum_j c_j B_j(r_i), r_i = ra + i*(rb-ra)/npts,
  * i = 0..npts.  Returns BSPATOM_ERR_BSPLVB where the reference STOPs. r[npts+1], u[npts+1]. */

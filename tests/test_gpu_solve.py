@@ -260,3 +260,63 @@ def test_invalid_requests():
     with pytest.raises(capi.BspAtomError):
         prob.eigvec(0, 0)                       # n0 is 1-based
     prob.close()
+
+
+# ---- the eigenvector block the KIND_PI >= 3 branch keeps, and Eigenvec_All.dat -----------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c1_lin", "bsp0", "rogers", "lin256"])
+def test_eigvecs_block_vs_lapack(name):
+    """Columns 1..nvec of DSYGV's 'V' output per channel (matrices.f90:248, kept as ctemp(:,1:ntemp,l) at :331).
+    Reference: LAPACK dsygv('V','U') -- the library the compiled reference links -- on the reference's own S, H_l
+    (golden fixtures).  Eigenvectors are defined up to sign: |c_gpu^T S c_ref| = 1, S-orthonormality, residual."""
+    import oracle as orc
+    g = load_golden(name)
+    inp = input_from_case(name)
+    prob = capi.Problem(inp)
+    nch, n = g["E"].shape
+    E, info = prob.solve(0, nch)
+    assert np.all(info == 0)
+    k = g["Sb"].shape[0]
+    nvec = min(n, 40)
+    for l in range(nch):
+        Su = orc.band_to_dense_upper(g["Sb"])
+        Hu = orc.band_to_dense_upper((g["Tb"] + g["Ub"][l]) + g["Vb"])
+        w, Zref, linfo = orc.dsygv(Hu, Su)
+        assert linfo == 0
+        S = Su + np.triu(Su, 1).T
+        H = Hu + np.triu(Hu, 1).T
+        Z = prob.eigvecs(l, 1, nvec)                                  # (nvec, n)
+        G = Z @ S @ Z.T
+        assert np.max(np.abs(G - np.eye(nvec))) < 1e-9
+        lam = np.max(np.abs(w))
+        for j in range(nvec):
+            res = np.max(np.abs(H @ Z[j] - E[l, j] * (S @ Z[j]))) / lam
+            assert res < 1e-12
+            # overlap with the reference vector unless its eigenvalue has a neighbour closer than 1e-7 relative
+            gap = min(abs(w[j] - w[j - 1]) if j > 0 else np.inf, abs(w[j + 1] - w[j]) if j + 1 < n else np.inf)
+            if gap > 1e-7 * lam:
+                ov = abs(Z[j] @ S @ Zref[:, j])
+                assert abs(ov - 1.0) < 1e-7, (name, l, j, ov)
+    note("eigvecs %s: %d channels x %d vectors, S-orthonormal to %.1e" % (name, nch, nvec, np.max(np.abs(G - np.eye(nvec)))))
+    prob.close()
+
+
+@pytest.mark.gpu
+def test_eigenvec_all_file_round_trip(tmp_path):
+    """Eigenvec_All.dat in the reference's layout (matrices.f90:366-378, FORMAT(I5,5000G20.10)) read back the way
+    READ_EIGENVEC does (ReadInputs.f90:792-830): header, channel records, 10 significant digits."""
+    from bspatom_amd import host
+    prob = capi.Problem(input_from_case("c1_lin"))
+    nch = load_golden("c1_lin")["E"].shape[0]
+    prob.solve(0, nch)
+    n1 = 12
+    path = tmp_path / "Eigenvec_All.dat"
+    host.write_eigenvec_all(str(path), prob, nch - 1, n1)
+    nfun, n1r, lmax, c = host.read_eigenvec_all(str(path))
+    assert (nfun, n1r, lmax) == (prob.nfun, n1, nch - 1)
+    for l in range(nch):
+        Z = prob.eigvecs(l, 1, n1)
+        assert np.max(np.abs(c[l] - Z)) <= 1e-9 * np.max(np.abs(Z))
+    first = open(path).readlines()[2]
+    assert len(first.rstrip("\n")) == 5 + 20 * prob.nfun
+    prob.close()

@@ -152,3 +152,26 @@ def test_channel_range_partitions():
                 seen += list(range(l0, l0 + nl))
             assert seen == list(range(lmax + 1))
     assert channel_range(3, 8, 0, per_rank=128) == (384, 128)
+
+
+def test_eigenvec_all_format_cpu(tmp_path):
+    """Eigenvec_All.dat writer/reader pair (matrices.f90:366-378 / ReadInputs.f90:792-830) without a GPU: records
+    are I5 followed by nfun G20.10 fields; values survive to 10 significant digits."""
+    from bspatom_amd import host
+
+    class FakeProblem:
+        nfun = 7
+        def eigvecs(self, l, n0, count):
+            rng = np.random.default_rng(l)
+            return rng.standard_normal((count, self.nfun)) * 10.0 ** rng.integers(-12, 3, size=(count, 1))
+
+    p = tmp_path / "Eigenvec_All.dat"
+    host.write_eigenvec_all(str(p), FakeProblem(), 2, 5)
+    lines = open(p).read().splitlines()
+    assert lines[0].split() == ["7", "5", "2"]
+    assert len(lines) == 1 + 3 * (1 + 5)
+    assert all(len(x) == 5 + 20 * 7 for x in lines[2:7])
+    nfun, n1, lmax, c = host.read_eigenvec_all(str(p))
+    for l in range(3):
+        Z = FakeProblem().eigvecs(l, 1, 5)
+        assert np.max(np.abs(c[l] - Z) / np.abs(Z)) < 1e-9
