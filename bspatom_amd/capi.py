@@ -33,7 +33,7 @@ class Sizes(C.Structure):
 
 EXPORTS = ["bspatom_input_defaults", "bspatom_device_count", "bspatom_host_setup", "bspatom_problem_create", "bspatom_problem_destroy",
            "bspatom_problem_sizes", "bspatom_problem_grid", "bspatom_assemble", "bspatom_solve", "bspatom_solve_dev",
-           "bspatom_eigvec", "bspatom_eigvecs", "bspatom_write_wf", "bspatom_last_timing", "bsp_dsygv_", "bspatom_stage_gemm",
+           "bspatom_eigvec", "bspatom_eigvecs", "bspatom_dipole_bands", "bspatom_write_wf", "bspatom_last_timing", "bsp_dsygv_", "bspatom_stage_gemm",
            "bspatom_stage_standard_form", "bspatom_stage_sy2sb", "bspatom_stage_sb2st", "bspatom_stage_bisect"]
 
 _lib = None
@@ -60,6 +60,7 @@ def lib():
         L.bspatom_solve_dev.argtypes = [vp, i32, i32, vp, vp]
         L.bspatom_eigvec.argtypes = [vp, i32, i32, vp]
         L.bspatom_eigvecs.argtypes = [vp, i32, i32, i32, vp]
+        L.bspatom_dipole_bands.argtypes = [vp, vp]
         L.bspatom_write_wf.argtypes = [vp, vp, i32, vp, vp]
         L.bspatom_last_timing.argtypes = [vp, vp]
         L.bspatom_stage_gemm.argtypes = [i32, i32, i32, i32, vp, lng, lng, lng, lng, vp, lng, lng, lng, lng,
@@ -152,6 +153,12 @@ class Problem:
         c = np.zeros(self.nfun)
         _chk(lib().bspatom_eigvec(self._h, l, n0, _p(c)), "bspatom_eigvec")
         return c
+
+    def dipole_bands(self):
+        """Full bands (3, 2k-1, nfun) of int B_i r B_j, int B_i (1/r) B_j, int B_i B_j' (rij of KIND_PI = 1, 2)."""
+        RB = np.zeros((3, 2 * self.k - 1, self.nfun))
+        _chk(lib().bspatom_dipole_bands(self._h, _p(RB)), "bspatom_dipole_bands")
+        return RB
 
     def eigvecs(self, l, n0, count):
         """Eigenvectors n0 .. n0+count-1 (1-based) of channel l: array (count, nfun), each S-normalised."""

@@ -191,6 +191,84 @@ __global__ __launch_bounds__(256) void band_kernel(int TI, int nfun, int k, int 
     }
 }
 
+// the dipole matrices MATRIX_SVT accumulates in the same quadrature loop and keeps in rij for
+// KIND_PI = 1, 2 (matrices.f90:141-144, 159-163): sumr = int B_i r B_j, sumc = int B_i (1/r) B_j,
+// sumd = int B_i B_j'.  The reference fills both triangles (jket = 1..nfun, :69) and they are not bit-symmetric,
+// so the full band is produced: RB[(c*(2k-1) + (d+k-1))*nfun + i] = X_c(i, i+d), d = -(k-1)..k-1, c = 0 (r),
+// 1 (1/r), 2 (d/dr).  Same staging, interval range (:71-72), point order and expression order as the reference.
+__global__ __launch_bounds__(256) void dipole_band_kernel(int TI, int nfun, int k, int ka, int nkp,
+                                                         const double *__restrict__ ptab,
+                                                         const int *__restrict__ leftv, double *__restrict__ RB)
+{
+    extern __shared__ double sm[];
+    const int W = 2 * k + 3, nd = 2 * k - 1;
+    const int i0 = blockIdx.x * TI;
+    const int ib0 = i0 + 1;
+    int nint = TI + k - 1;
+    if (ib0 + nint - 1 > nkp - 1) nint = nkp - 1 - ib0 + 1;
+    const int npts = nint * ka;
+    double *tab = sm;
+    int *lf = reinterpret_cast<int *>(sm + (size_t)(TI + k - 1) * ka * W);
+    for (int idx = threadIdx.x; idx < npts * W; idx += blockDim.x)
+        tab[idx] = ptab[(size_t)(ib0 - 1) * ka * W + idx];
+    for (int idx = threadIdx.x; idx < npts; idx += blockDim.x) lf[idx] = leftv[(ib0 - 1) * ka + idx];
+    __syncthreads();
+    const int nrow = (nfun - i0 < TI) ? (nfun - i0) : TI;
+    for (int it = threadIdx.x; it < TI * nd; it += blockDim.x) {
+        const int ii = it % TI, dd = it / TI, d = dd - (k - 1);
+        if (ii >= nrow) continue;
+        const int ibra = i0 + ii + 1, jket = ibra + d;        // 1-based
+        const size_t off = (size_t)dd * nfun + (ibra - 1);
+        double sumr = 0.0, sumc = 0.0, sumd = 0.0;
+        if (jket >= 1 && jket <= nfun) {
+            const int ibetmin = ibra > jket ? ibra : jket;                    // matrices.f90:71
+            const int ibetmax = (ibra < jket ? ibra : jket) + k - 1;          // :72
+            for (int ibet = ibetmin; ibet <= ibetmax; ++ibet) {
+                const double *eb = tab + (size_t)(ibet - ib0) * ka * W;
+                const int *lb = lf + (ibet - ib0) * ka;
+                for (int g = 0; g < ka; ++g) {
+                    const double *e = eb + g * W;
+                    const int left = lb[g];
+                    int ifun = ibra - (left - k), jfun = jket - (left - k);
+                    ifun = ifun < 1 ? 1 : (ifun > k ? k : ifun);
+                    jfun = jfun < 1 ? 1 : (jfun > k ? k : jfun);
+                    const double fbra = e[ifun - 1], fket = e[jfun - 1], dfket = e[k + jfun - 1];
+                    const double r = e[2 * k], dr = e[2 * k + 1];
+                    sumc = sumc + fbra * (1.0 / r) * fket * dr;               // :141
+                    sumd = sumd + fbra * dfket * dr;                          // :142
+                    sumr = sumr + fbra * r * fket * dr;                       // :144
+                }
+            }
+        }
+        RB[off] = sumr;
+        RB[(size_t)nd * nfun + off] = sumc;
+        RB[(size_t)2 * nd * nfun + off] = sumd;
+    }
+}
+
+int launch_dipole_bands(int nfun, int k, int ka, int nkp, const double *d_ptab, const int *d_left, double *d_RB,
+                        hipStream_t st)
+{
+    const int W = 2 * k + 3;
+    int TI = 32;
+    size_t lds = 0;
+    for (; TI >= 4; TI /= 2) {
+        lds = (size_t)(TI + k - 1) * ka * W * sizeof(double) + (size_t)(TI + k - 1) * ka * sizeof(int);
+        if (lds <= 150 * 1024) break;
+    }
+    if (TI < 4) return BSP_ERR_UNSUPPORTED;
+    static bool attr = false;
+    if (!attr) {
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dipole_band_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(dipole_band_kernel, dim3((nfun + TI - 1) / TI), dim3(256), lds, st, TI, nfun, k, ka, nkp, d_ptab, d_left,
+                       d_RB);
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
+
 int launch_point_table(int nkp, int k, int ka, int nfun, const double *d_rt, const double *d_aind,
                        const double *d_xg, const double *d_wg, const double *d_vpot, double *d_ptab,
                        int *d_left, int *d_status, hipStream_t st)

@@ -195,6 +195,30 @@ static int check_status(bspatom_problem *p)
     return st;
 }
 
+extern "C" int bspatom_dipole_bands(bspatom_problem *p, double *RB)
+{
+    if (!p || !RB) return BSP_ERR_ARG;
+    const HostSetup &h = p->hs;
+    BSP_HIP(hipSetDevice(p->device));
+    int rc;
+    if (!p->ptab_ready) {
+        if ((rc = launch_point_table(h.nkp, h.k, h.ka, h.nfun, p->d_rt, p->d_aind, p->d_xg, p->d_wg, p->d_vpot,
+                                     p->d_ptab, p->d_left, p->d_status, p->st))) return rc;
+        p->ptab_ready = true;
+    }
+    const size_t cnt = (size_t)3 * (2 * h.k - 1) * h.nfun;
+    double *d_RB = nullptr;
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&d_RB), cnt * sizeof(double)));
+    rc = launch_dipole_bands(h.nfun, h.k, h.ka, h.nkp, p->d_ptab, p->d_left, d_RB, p->st);
+    hipError_t e = hipSuccess;
+    if (!rc) e = hipMemcpyAsync(RB, d_RB, cnt * sizeof(double), hipMemcpyDeviceToHost, p->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->st);
+    hipFree(d_RB);
+    if (rc) return rc;
+    BSP_HIP(e);
+    return check_status(p);
+}
+
 extern "C" int bspatom_assemble(bspatom_problem *p, int l0, int nl, double *SB, double *HB)
 {
     if (!p || nl <= 0 || l0 < 0) return BSP_ERR_ARG;

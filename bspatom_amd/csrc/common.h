@@ -67,6 +67,8 @@ int launch_point_table(int nkp, int k, int ka, int nfun, const double *d_rt, con
 int launch_assemble_bands(int nfun, int k, int ka, int nkp, int kind_pot, const double *d_bl, int l0,
                           int nl, const double *d_ptab, const int *d_left, double *d_SB, double *d_HB,
                           hipStream_t st);
+int launch_dipole_bands(int nfun, int k, int ka, int nkp, const double *d_ptab, const int *d_left, double *d_RB,
+                        hipStream_t st);
 // bandchol.hip
 int launch_band_cholesky(int n, int k, const double *d_SB, double *d_UB, double *d_rdiag, int *d_info,
                          hipStream_t st);

@@ -64,6 +64,14 @@ int bspatom_problem_grid(const bspatom_problem *p, double *rt, double *aind, dou
  * (results stay on the device for bspatom_solve). */
 int bspatom_assemble(bspatom_problem *p, int l0, int nl, double *SB, double *HB);
 
+/* SURVEY 8(f).2 -- the dipole matrices that MATRIX_SVT accumulates in the same quadrature loop and keeps in
+ * rij for KIND_PI = 1, 2 (matrices.f90:141-144, 159-163): c = 0: int B_i r B_j dr (rij(:,:,1), length gauge),
+ * c = 1: int B_i (1/r) B_j dr and c = 2: int B_i B_j' dr (rij(:,:,1), rij(:,:,2), velocity gauge).  The
+ * reference fills both triangles and they are not bit-symmetric, so the FULL band is returned:
+ * RB[(c*(2k-1) + (d+k-1))*nfun + i] = X_c(i, i+d), 0-based i, d = -(k-1)..k-1.  Bit-identical to the
+ * reference's rij on the band (which is all of it).  RB: 3*(2k-1)*nfun doubles. */
+int bspatom_dipole_bands(bspatom_problem *p, double *RB);
+
 /* SOLVE_SYSTEM's l-loop (matrices.f90:242-265): assembly + DSYGV eigenvalues for channels
  * l0 .. l0+nl-1.  E[l*nfun + i] ascending per channel (column-major Enl(nfun,0:lmax), :230).
  * info[l]: 0 ok; nfun+i: leading minor i of S not positive definite (DSYGV convention, :250-254). */

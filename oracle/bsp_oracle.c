@@ -397,6 +397,69 @@ int orc_assemble_bands(const orc_cfg *c, const double *rt0, const double *aind,
     return ORC_OK;
 }
 
+/* SURVEY 8(f).2 -- the dipole matrices MATRIX_SVT accumulates in the same quadrature loop and keeps in
+ * rij for KIND_PI = 1, 2 (matrices.f90:141-144, 159-163):
+ *   RB[0] = sumr = int B_i r B_j dr        -> rij(:,:,1) for KIND_PI = 1 (length gauge)
+ *   RB[1] = sumc = int B_i (1/r) B_j dr    -> rij(:,:,1) for KIND_PI = 2 (velocity gauge)
+ *   RB[2] = sumd = int B_i B_j' dr         -> rij(:,:,2) for KIND_PI = 2
+ * The reference fills both triangles (jket = 1..nfun, matrices.f90:69) and they are not bit-symmetric, so the
+ * FULL band is returned: RB[(c*(2k-1) + (d + k-1))*nfun + (i-1)] = X_c(i, i+d), d = -(k-1)..k-1; same
+ * interval range (ibetmin..ibetmax, :71-72), point order and expression order as the reference
+ * (left to right: ((fbra * (1/r)) * fket) * dr). */
+int orc_dipole_bands(const orc_cfg *c, const double *rt0, const double *aind,
+                     const double *xg, const double *wg, double *RB)
+{
+    const double *rt = rt0 - 1;
+    int nfun = c->nfun, k = c->k, ka = c->ka, nkp = c->nkp;
+    int npt = (nkp - 1) * ka, nd = 2 * k - 1;
+    double *tb = (double *)malloc(sizeof(double) * (size_t)npt * (2 * k + 3));
+    int *tl = (int *)malloc(sizeof(int) * npt);
+    for (int ibet = 1; ibet <= nkp - 1; ++ibet) {
+        double f1 = (rt[ibet + 1] + rt[ibet]) / 2.0;
+        double f2 = (rt[ibet + 1] - rt[ibet]) / 2.0;
+        for (int igl = 1; igl <= ka; ++igl) {
+            int p = (ibet - 1) * ka + (igl - 1);
+            double *e = tb + (size_t)p * (2 * k + 3);
+            double r = f1 + xg[igl - 1] * f2, dr = f2 * wg[igl - 1];
+            int left;
+            int st = orc_bspall(c, rt0, aind, r, &left, e, e + k);
+            if (st) { free(tb); free(tl); return st; }
+            if (r == 0.0) r = DBL_EPSILON;
+            e[2 * k] = r; e[2 * k + 1] = dr; e[2 * k + 2] = 0.0;
+            tl[p] = left;
+        }
+    }
+    for (int d = -(k - 1); d <= k - 1; ++d) {
+        for (int ibra = 1; ibra <= nfun; ++ibra) {
+            int jket = ibra + d;
+            size_t off = (size_t)(d + k - 1) * nfun + (ibra - 1);
+            double sumr = 0.0, sumc = 0.0, sumd = 0.0;
+            if (jket >= 1 && jket <= nfun) {
+                int ibetmin = ibra > jket ? ibra : jket;                     /* :71 */
+                int ibetmax = (ibra < jket ? ibra : jket) + k - 1;           /* :72 */
+                for (int ibet = ibetmin; ibet <= ibetmax; ++ibet) {
+                    for (int igl = 1; igl <= ka; ++igl) {
+                        int p = (ibet - 1) * ka + (igl - 1);
+                        const double *e = tb + (size_t)p * (2 * k + 3);
+                        int left = tl[p];
+                        int ifun = ibra - (left - k), jfun = jket - (left - k);
+                        double fbra = e[ifun - 1], fket = e[jfun - 1], dfket = e[k + jfun - 1];
+                        double r = e[2 * k], dr = e[2 * k + 1];
+                        sumc = sumc + fbra * (1.0 / r) * fket * dr;     /* :141 */
+                        sumd = sumd + fbra * dfket * dr;                /* :142 */
+                        sumr = sumr + fbra * r * fket * dr;             /* :144 */
+                    }
+                }
+            }
+            RB[off] = sumr;
+            RB[(size_t)nd * nfun + off] = sumc;
+            RB[(size_t)2 * nd * nfun + off] = sumd;
+        }
+    }
+    free(tb); free(tl);
+    return ORC_OK;
+}
+
 /* Bsp_Atom.f90:118-146 -- tabulate u(r) = sum_j c_j B_j(r) on npts+1 points. */
 int orc_write_wf(const orc_cfg *c, const double *rt0, const double *ci, int n,
                  int npts, double *r_out, double *u_out)

@@ -111,6 +111,17 @@ def assemble_bands(c, rt, aind, xg, wg, l0=0, nl=None):
     return SB, HB
 
 
+def dipole_bands(c, rt, aind, xg, wg):
+    """Full bands [3][2k-1][nfun] (RB[c][d+k-1][i] = X_c(i, i+d)) of int B_i r B_j, int B_i (1/r) B_j,
+    int B_i B_j' as MATRIX_SVT accumulates them (matrices.f90:141-144; both triangles, not bit-symmetric)."""
+    RB = np.zeros((3, 2 * c.k - 1, c.nfun))
+    lib().orc_dipole_bands.argtypes = [C.c_void_p] * 6
+    st = lib().orc_dipole_bands(C.byref(c), _p(rt), _p(aind), _p(xg), _p(wg), _p(RB))
+    if st:
+        raise RuntimeError("oracle: FATAL ERROR - BSPLVB (status %d)" % st)
+    return RB
+
+
 def band_to_dense_upper(B):
     k, n = B.shape
     M = np.zeros((n, n))

@@ -25,6 +25,13 @@
       WRITE(91) Aind(1:nfun,1:2)
       WRITE(91) Sij, Tij, Vij, Uij
       CLOSE(91)
+!     KIND_PI = 1, 2: the dipole matrices MATRIX_SVT leaves in rij (matrices.f90:159-163), for SURVEY 8(f).2
+      IF( ALLOCATED(rij) .AND. KIND_PI >= 1 .AND. KIND_PI <= 2 ) THEN
+        OPEN(UNIT=92, FILE='ref_rij.bin', ACCESS='STREAM', FORM='UNFORMATTED', ACTION='WRITE')
+        WRITE(92) nfun, KIND_PI
+        WRITE(92) rij
+        CLOSE(92)
+      END IF
       CALL SOLVE_SYSTEM
       CALL SYSTEM_CLOCK(c2)
       WRITE(6,'(A,F12.4)') 'REF_TIME_MATRIX_SVT_S ', DBLE(c1-c0)/DBLE(crate)

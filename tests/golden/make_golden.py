@@ -63,6 +63,52 @@ BIG = {
     "c4_4096": (nml("KIND_GRID=0 ra=0.0D0 rb=800.0D0 k=9 nfun=4096", "n0_ini=1 l_ini=0 l_fin=1 Zatom=1.0D0"), False),
 }
 
+# dipole matrices rij that MATRIX_SVT keeps for KIND_PI = 1 (length) / 2 (velocity).  name -> (namelist, KIND_PI)
+def nml_pi(bsp, tise, kind_pi):
+    return "&VARS_BSP %s &end\n&VARS_TISE %s &end\n&VARS_FIELD KIND_PI=%d Eph=0.5D0 I0=1.0D14 &end\n" % (bsp, tise, kind_pi)
+
+DIPOLE = {
+    "dip_len_lin": (nml_pi("KIND_GRID=0 ra=0.0D0 rb=50.0D0 k=7 nfun=64", "n0_ini=1 l_ini=0 l_fin=1 Zatom=1.0D0", 1), 1),
+    "dip_vel_lin": (nml_pi("KIND_GRID=0 ra=0.0D0 rb=50.0D0 k=7 nfun=64", "n0_ini=1 l_ini=0 l_fin=1 Zatom=1.0D0", 2), 2),
+    "dip_len_exp": (nml_pi("KIND_GRID=1 ra=0.0D0 rb=200.0D0 k=9 nfun=96", "n0_ini=1 l_ini=0 l_fin=1 Zatom=1.0D0", 1), 1),
+    "dip_vel_exp": (nml_pi("KIND_GRID=1 ra=0.0D0 rb=200.0D0 k=9 nfun=96", "n0_ini=1 l_ini=0 l_fin=1 Zatom=1.0D0", 2), 2),
+}
+
+def run_dipole(name, text, kind_pi):
+    inp = os.path.join(HERE, "inputs", name + ".inp")
+    with open(inp, "w") as f:
+        f.write("! golden-fixture input '%s' (generated by make_golden.py)\n" % name)
+        f.write(text)
+    with tempfile.TemporaryDirectory(prefix="bspgold.") as tmp:
+        with open(inp) as fin:
+            p = subprocess.run([REFX], stdin=fin, cwd=tmp, capture_output=True, text=True)
+        if p.returncode != 0:
+            raise RuntimeError("reference failed on %s:\n%s\n%s" % (name, p.stdout[-2000:], p.stderr[-2000:]))
+        raw = open(os.path.join(tmp, "ref_dump.bin"), "rb").read()
+        hdr = np.frombuffer(raw[:32], dtype=np.int32)
+        nfun, k, ka, nkp, nointv, nbc1, nbc2, lmax = [int(v) for v in hdr]
+        rr = open(os.path.join(tmp, "ref_rij.bin"), "rb").read()
+        h2 = np.frombuffer(rr[:8], dtype=np.int32)
+        assert int(h2[0]) == nfun and int(h2[1]) == kind_pi
+        R = np.frombuffer(rr[8:], dtype=np.float64).reshape(2, nfun, nfun)       # rij(:,:,m) column-major -> R[m][j][i]
+        r1, r2 = R[0].T, R[1].T
+        # MATRIX_SVT fills BOTH triangles (jket = 1..nfun, matrices.f90:69) and the two are not bit-symmetric
+        # (((fbra*r)*fket)*dr vs ((fket*r)*fbra)*dr; int B_i B_j' is not symmetric at all): full band, 2k-1 diagonals
+        def full_band(M):
+            B = np.zeros((2 * k - 1, nfun))
+            for d in range(-(k - 1), k):
+                i = np.arange(max(0, -d), min(nfun, nfun - d))
+                B[d + k - 1, i] = M[i, i + d]
+            return B
+        out = dict(sizes=np.array([nfun, k, ka, nkp, nointv, nbc1, nbc2, lmax]), kind_pi=np.array([kind_pi]),
+                   r1f=full_band(r1), r2f=full_band(r2),
+                   outside_band_max=np.array([max(np.max(np.abs(np.tril(r1, -k))), np.max(np.abs(np.tril(r2, -k))),
+                                                  np.max(np.abs(np.triu(r1, k))), np.max(np.abs(np.triu(r2, k))))]),
+                   namelist=np.array(open(inp).read()))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("%-12s nfun=%4d k=%2d KIND_PI=%d  |r1|max %.6g |r2|max %.6g outside band %.1e" % (
+        name, nfun, k, kind_pi, np.max(np.abs(out["r1f"])), np.max(np.abs(out["r2f"])), out["outside_band_max"][0]), flush=True)
+
 def upper_band(M, k):
     n = M.shape[0]
     B = np.zeros((k, n))
@@ -140,8 +186,16 @@ def main():
     cases = dict(CASES)
     if "--big" in args:
         cases.update(BIG); args.remove("--big")
+    if "--dipole" in args:
+        args.remove("--dipole")
+        for name in (args or list(DIPOLE)):
+            run_dipole(name, *DIPOLE[name])
+        return
     sel = args or list(cases)
     for name in sel:
+        if name in DIPOLE:
+            run_dipole(name, *DIPOLE[name])
+            continue
         text, mats = {**CASES, **BIG}[name]
         run_case(name, text, mats)
     man = {

@@ -191,3 +191,24 @@ def test_bisect(n, batch):
         note("bisect n %d b%d err %.2e" % (n, b, err))
         assert np.all(np.diff(w[b]) >= 0)
         assert err < 1e-13      # scipy (LAPACK QL) itself carries O(n eps |T|) error
+
+
+# ---- dipole matrices accumulated in MATRIX_SVT's quadrature loop -----------------------------
+DIPOLE_CASES = ["dip_len_lin", "dip_vel_lin", "dip_len_exp", "dip_vel_exp"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", DIPOLE_CASES)
+def test_dipole_bands_bit_exact(name):
+    """rij(:,:,1:2) as the COMPILED reference leaves them for KIND_PI = 1 (length: int B_i r B_j) and KIND_PI = 2
+    (velocity: int B_i (1/r) B_j, int B_i B_j'), matrices.f90:141-144,159-163 -- full band, bit for bit."""
+    g = load_golden(name)
+    prob = capi.Problem(input_from_case(name))
+    RB = prob.dipole_bands()
+    if int(g["kind_pi"][0]) == 1:
+        assert np.array_equal(RB[0], g["r1f"])
+    else:
+        assert np.array_equal(RB[1], g["r1f"])
+        assert np.array_equal(RB[2], g["r2f"])
+    assert float(g["outside_band_max"][0]) == 0.0            # the band is the whole matrix
+    prob.close()

@@ -131,3 +131,21 @@ def test_rydberg_known_answers():
     assert abs(g["E"][2, 0] - (-0.0555555554481607)) < 1e-14
     g = load_golden("c1_exp")
     assert abs(g["E"][0, 0] - (-0.499999999999882)) < 1e-14
+
+
+@pytest.mark.parametrize("name", ["dip_len_lin", "dip_vel_lin", "dip_len_exp", "dip_vel_exp"])
+def test_oracle_dipole_bands_bit_exact(name):
+    """the oracle's restatement of the dipole sums against the compiled reference's rij."""
+    import oracle as orc
+    from bspatom_amd.namelist import read_namelists
+    g = load_golden(name)
+    nl = read_namelists(str(g["namelist"]))
+    kw = {}
+    kw.update(nl["vars_bsp"]); kw.update(nl["vars_tise"])
+    c = orc.make_cfg(**kw)
+    rt, aind, xg, wg = orc.grid(c)
+    RB = orc.dipole_bands(c, rt, aind, xg, wg)
+    if int(g["kind_pi"][0]) == 1:
+        assert np.array_equal(RB[0], g["r1f"])
+    else:
+        assert np.array_equal(RB[1], g["r1f"]) and np.array_equal(RB[2], g["r2f"])
