@@ -19,6 +19,7 @@
 // after a sub-panel is factored its block reflector (I - V_s T_s^T V_s^T) is applied to the
 // remaining panel columns CW = 4 at a time, streaming them through registers.
 #include "common.h"
+#include <vector>
 
 namespace bsp {
 
@@ -624,8 +625,9 @@ struct Sy2sbLane {                       // one pipeline: main + high-priority s
     hipEvent_t evA = nullptr, evB = nullptr, done = nullptr;
 };
 
-static int sy2sb_pipeline(int npad, int batch, double *d_A, const Sy2sbWork &w, hipStream_t st, const Sy2sbLane &ln,
-                          int lookahead)
+// one panel step of one pipeline (p = -1: the first panel's QR, T, W)
+static int sy2sb_panel(int npad, int batch, double *d_A, const Sy2sbWork &w, hipStream_t st, const Sy2sbLane &ln,
+                       int lookahead, int p)
 {
     hipStream_t side = ln.side;
     hipEvent_t evA = ln.evA, evB = ln.evB;
@@ -634,8 +636,8 @@ static int sy2sb_pipeline(int npad, int batch, double *d_A, const Sy2sbWork &w, 
     const int P = npad / NB - 1;
     int rc;
     if (P <= 0) return BSP_OK;
-    if ((rc = panel_and_W(npad, 0, batch, d_A, w.buf, w.tau, w, st))) return rc;
-    for (int p = 0; p < P; ++p) {
+    if (p < 0) return panel_and_W(npad, 0, batch, d_A, w.buf, w.tau, w, st);
+    {
         const int c0 = p * NB, r0 = c0 + NB, m = npad - r0;
         double *buf = (p & 1) ? w.buf2 : w.buf;
         double *bufn = (p & 1) ? w.buf : w.buf2;
@@ -675,6 +677,16 @@ static int sy2sb_pipeline(int npad, int batch, double *d_A, const Sy2sbWork &w, 
     return BSP_OK;
 }
 
+static int sy2sb_pipeline(int npad, int batch, double *d_A, const Sy2sbWork &w, hipStream_t st, const Sy2sbLane &ln,
+                          int lookahead)
+{
+    const int P = npad / NB - 1;
+    int rc;
+    for (int p = -1; p < P; ++p)
+        if ((rc = sy2sb_panel(npad, batch, d_A, w, st, ln, lookahead, p))) return rc;
+    return BSP_OK;
+}
+
 // The per-panel chain QR -> T, W -> SYMM -> K, Z -> SYR2K part 1 -> next QR is serial within a channel, and the
 // panel QR (one workgroup per channel) cannot fill the chip.  The channels are therefore split into groups that run
 // the whole pipeline independently on their own streams: while one group factors a panel the other keeps the
@@ -694,6 +706,9 @@ int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipS
         if (groups > MAXG) groups = MAXG;
         int plo = 0, phi = 0;                      // the latency-bound panel work gets the high-priority queue
         BSP_HIP(hipDeviceGetStreamPriorityRange(&plo, &phi));
+        // (Giving the panel streams compute units of their own through CU masks -- a panel-QR workgroup needs a whole
+        // CU and waits between GEMM workgroups that take half a CU each -- was tried: 32/64/96 reserved CUs cost
+        // 20-37 % of the stage; the GEMMs need every CU's memory pipeline.)
         for (int g = 0; g < MAXG; ++g) {
             BSP_HIP(hipStreamCreateWithFlags(&lanes[g].main, hipStreamNonBlocking));
             BSP_HIP(hipStreamCreateWithPriority(&lanes[g].side, hipStreamNonBlocking, phi));
@@ -709,18 +724,28 @@ int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipS
     BSP_HIP(hipEventRecord(fork, st));
     const size_t bsA = (size_t)npad * npad, bsBuf = (size_t)npad * 3 * NB, bsW = (size_t)npad * NB, bsS = (size_t)NB * NB;
     int rc = BSP_OK, c0 = 0;
+    Sy2sbWork wg[MAXG];
+    int cnt[MAXG], first[MAXG];
     for (int g = 0; g < ng; ++g) {
-        const int cnt = batch / ng + (g < batch % ng ? 1 : 0);
-        Sy2sbWork wg = w;
-        wg.buf = w.buf + c0 * bsBuf; wg.buf2 = w.buf2 + c0 * bsBuf; wg.W = w.W + c0 * bsW;
-        wg.G = w.G + c0 * bsS; wg.T = w.T + c0 * bsS; wg.Kmat = w.Kmat + c0 * bsS;
-        wg.tau = w.tau + (size_t)c0 * NB; wg.tau2 = w.tau2 + (size_t)c0 * NB;
-        wg.part = w.part + (size_t)c0 * SY2SB_SPLITK * bsS;      // [splits][cnt][nb][nb] inside this group's share
+        cnt[g] = batch / ng + (g < batch % ng ? 1 : 0);
+        first[g] = c0;
+        wg[g] = w;
+        wg[g].buf = w.buf + c0 * bsBuf; wg[g].buf2 = w.buf2 + c0 * bsBuf; wg[g].W = w.W + c0 * bsW;
+        wg[g].G = w.G + c0 * bsS; wg[g].T = w.T + c0 * bsS; wg[g].Kmat = w.Kmat + c0 * bsS;
+        wg[g].tau = w.tau + (size_t)c0 * NB; wg[g].tau2 = w.tau2 + (size_t)c0 * NB;
+        wg[g].part = w.part + (size_t)c0 * SY2SB_SPLITK * bsS;      // [splits][cnt][nb][nb] inside this group's share
         BSP_HIP(hipStreamWaitEvent(lanes[g].main, fork, 0));
-        if ((rc = sy2sb_pipeline(npad, cnt, d_A + c0 * bsA, wg, lanes[g].main, lanes[g], lookahead))) return rc;
+        c0 += cnt[g];
+    }
+    // enqueue panel by panel, the groups alternating: the host needs ~12 ms to enqueue one group's ~800 launches,
+    // and a group whose launches all come after the other's starts (and ends) that much later
+    const int P = npad / NB - 1;
+    for (int p = -1; p < P; ++p)
+        for (int g = 0; g < ng; ++g)
+            if ((rc = sy2sb_panel(npad, cnt[g], d_A + first[g] * bsA, wg[g], lanes[g].main, lanes[g], lookahead, p))) return rc;
+    for (int g = 0; g < ng; ++g) {
         BSP_HIP(hipEventRecord(lanes[g].done, lanes[g].main));
         BSP_HIP(hipStreamWaitEvent(st, lanes[g].done, 0));
-        c0 += cnt;
     }
     return BSP_OK;
 }
