@@ -34,6 +34,9 @@
       END IF
       CALL SOLVE_SYSTEM
       CALL SYSTEM_CLOCK(c2)
+!     (Continuing into TRANS_AMP / CROSS_SECTIONS for KIND_PI = 1, 2, as PROGRAM BSP_ATOM_PI does, is not
+!     possible with this build: TRANS_AMP prints Enl(1,lf), PhotoIon.f90:45, which SOLVE_SYSTEM allocates for
+!     KIND_PI >= 3 only -- the compiled reference segfaults there, so no amplitude fixtures exist.)
       WRITE(6,'(A,F12.4)') 'REF_TIME_MATRIX_SVT_S ', DBLE(c1-c0)/DBLE(crate)
       WRITE(6,'(A,F12.4)') 'REF_TIME_SOLVE_SYSTEM_S ', DBLE(c2-c1)/DBLE(crate)
       END PROGRAM REF_DUMP
