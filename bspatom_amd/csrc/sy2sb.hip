@@ -508,22 +508,32 @@ __global__ __launch_bounds__(PQ_THREADS) void panel_qr2_kernel(int npad, int r0,
 __global__ __launch_bounds__(64) void form_T_kernel(const double *__restrict__ Gall,
                                                    const double *__restrict__ tauall, double *Tall)
 {
-    __shared__ double T[NB][NB + 1];
-    __shared__ double G[NB][NB + 1];
+    // Thread i owns row i of T.  Column j needs s_i = sum_{p=i}^{j-1} T(i,p) G(p,j); T is upper triangular and its
+    // columns >= j are still zero, so the sum may run over ALL p: a fixed trip count, four independent accumulators
+    // and 16-byte LDS reads (row i of T and row j of G^T are contiguous) instead of a dependent chain of single reads
+    // with data-dependent bounds (the first version: 200 us per panel, on the critical chain of the stage).
+    __shared__ __attribute__((aligned(16))) double T[NB][NB + 2];
+    __shared__ __attribute__((aligned(16))) double Gt[NB][NB + 2];       // Gt[j][p] = G(p, j)
     const int i = threadIdx.x;
     const size_t ch = blockIdx.x;
     const double *Gg = Gall + ch * NB * NB;
     const double *tau = tauall + ch * NB;
     double *Tg = Tall + ch * NB * NB;
-    for (int j = 0; j < NB; ++j) { G[i][j] = Gg[i * NB + j]; T[i][j] = 0.0; }
+    for (int j = 0; j < NB; ++j) { Gt[j][i] = Gg[i * NB + j]; T[i][j] = 0.0; }
     __syncthreads();
     for (int j = 0; j < NB; ++j) {
-        double s = 0.0;
-        if (i < j)
-            for (int p = i; p < j; ++p) s += T[i][p] * G[p][j];
-        __syncthreads();
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int p = 0; p < NB; p += 4) {
+            const double2 t01 = *reinterpret_cast<const double2 *>(&T[i][p]);
+            const double2 t23 = *reinterpret_cast<const double2 *>(&T[i][p + 2]);
+            const double2 g01 = *reinterpret_cast<const double2 *>(&Gt[j][p]);
+            const double2 g23 = *reinterpret_cast<const double2 *>(&Gt[j][p + 2]);
+            s0 += t01.x * g01.x; s1 += t01.y * g01.y; s2 += t23.x * g23.x; s3 += t23.y * g23.y;
+        }
         const double tj = tau[j];
-        if (i < j) T[i][j] = -tj * s;
+        __syncthreads();
+        if (i < j) T[i][j] = -tj * ((s0 + s1) + (s2 + s3));
         if (i == j) T[i][j] = tj;
         __syncthreads();
     }
