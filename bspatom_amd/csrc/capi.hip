@@ -28,6 +28,13 @@ struct bspatom_problem {
     double *d_vwork = nullptr, *d_vec = nullptr, *d_wfr = nullptr, *d_wfu = nullptr, *d_Esel = nullptr;
     int *d_chan = nullptr;
     int wf_cap = 0;
+    // the eigenvector the reference consumes, Hij(:, n0_ini) of channel l_ini (matrices.f90:267), computed on a side
+    // stream while the batched bisection runs; bspatom_eigvec returns it when asked for exactly that state
+    hipStream_t st2 = nullptr;
+    hipEvent_t evx = nullptr;
+    double *d_pvec = nullptr, *d_pE = nullptr;
+    int *d_pinfo = nullptr;
+    int pre_l = -1, pre_n0 = -1, pre_ch = 0;
     // last solve
     int last_l0 = 0, last_nl = 0;
     hipEvent_t ev[7];
@@ -81,6 +88,9 @@ extern "C" void bspatom_problem_destroy(bspatom_problem *p)
     hipFree(p->d_rt); hipFree(p->d_aind); hipFree(p->d_xg); hipFree(p->d_wg); hipFree(p->d_vpot);
     hipFree(p->d_bl); hipFree(p->d_ptab); hipFree(p->d_left); hipFree(p->d_status); hipFree(p->d_info);
     hipFree(p->d_vwork); hipFree(p->d_vec); hipFree(p->d_wfr); hipFree(p->d_wfu); hipFree(p->d_Esel); hipFree(p->d_chan);
+    hipFree(p->d_pvec); hipFree(p->d_pE); hipFree(p->d_pinfo);
+    if (p->st2) hipStreamDestroy(p->st2);
+    if (p->evx) hipEventDestroy(p->evx);
     for (auto &e : p->ev) hipEventDestroy(e);
     hipStreamDestroy(p->st);
     delete p;
@@ -255,6 +265,17 @@ int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const d
 }
 }  // namespace bsp
 
+static int ensure_vec_scratch(bspatom_problem *p)
+{
+    const HostSetup &h = p->hs;
+    if (p->d_vwork) return BSP_OK;
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_vwork), invit_work_doubles(h.nfun, h.k) * sizeof(double)));
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_vec), (size_t)h.nfun * sizeof(double)));
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_chan), sizeof(int)));
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_Esel), sizeof(double)));
+    return BSP_OK;
+}
+
 static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, double *E_host, int32_t *info)
 {
     if (!p || nl <= 0 || l0 < 0) return BSP_ERR_ARG;
@@ -270,6 +291,31 @@ static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, dou
     PipeBufs pb{p->d_UB, p->d_rdiag, p->d_Y, p->d_C, p->d_AB, p->d_d, p->d_e, p->d_work, p->d_info, p->d_status, p->d_sbctl};
     double *Eout = E_dev_out ? E_dev_out : p->d_E;
     if ((rc = pipeline_enqueue(n, np, h.k, nl, p->d_SB, p->d_HB, pb, Eout, p->st, &p->ev[1]))) return rc;
+    // The consumed eigenvector (l_ini, n0_ini): its eigenvalue alone by multisection as soon as the tridiagonal
+    // matrices exist (ev[4] = after sb2st), then the inverse iteration, on a second stream beside the batched bisection.
+    p->pre_l = -1;
+    const int tl = h.in.l_ini, tn0 = h.in.n0_ini;
+    if (tl >= l0 && tl < l0 + nl && tn0 >= 1 && tn0 <= n && getenv("BSP_NO_EIGVEC_PREFETCH") == nullptr) {
+        if (!p->st2) {
+            BSP_HIP(hipStreamCreateWithFlags(&p->st2, hipStreamNonBlocking));
+            BSP_HIP(hipEventCreateWithFlags(&p->evx, hipEventDisableTiming));
+            BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_pvec), (size_t)n * sizeof(double)));
+            BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_pE), sizeof(double)));
+            BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_pinfo), sizeof(int)));
+        }
+        if ((rc = ensure_vec_scratch(p))) return rc;
+        p->pre_ch = tl - l0;                               // member: must outlive the asynchronous copy
+        const int ch = p->pre_ch;
+        BSP_HIP(hipStreamWaitEvent(p->st2, p->ev[4], 0));
+        BSP_HIP(hipMemcpyAsync(p->d_chan, &p->pre_ch, sizeof(int), hipMemcpyHostToDevice, p->st2));
+        BSP_HIP(hipMemsetAsync(p->d_pinfo, 0, sizeof(int), p->st2));
+        if ((rc = launch_bisect_one(n, p->d_d + (size_t)ch * np, p->d_e + (size_t)ch * np, tn0 - 1, p->d_pE, p->st2))) return rc;
+        if ((rc = launch_inverse_iteration(n, h.k, 1, p->d_SB, p->d_HB, p->d_chan, p->d_pE, p->d_vwork, p->d_pvec,
+                                           p->d_pinfo, p->st2))) return rc;
+        BSP_HIP(hipEventRecord(p->evx, p->st2));
+        BSP_HIP(hipStreamWaitEvent(p->st, p->evx, 0));
+        p->pre_l = tl; p->pre_n0 = tn0;
+    }
     if (E_dev_out)   // keep a copy for bspatom_eigvec
         BSP_HIP(hipMemcpyAsync(p->d_E, E_dev_out, (size_t)nl * n * sizeof(double), hipMemcpyDeviceToDevice, p->st));
     BSP_HIP(hipStreamSynchronize(p->st));
@@ -316,12 +362,12 @@ extern "C" int bspatom_eigvec(bspatom_problem *p, int l, int n0, double *c)
     const int n = h.nfun;
     if (l < p->last_l0 || l >= p->last_l0 + p->last_nl || n0 < 1 || n0 > n) return BSP_ERR_ARG;
     BSP_HIP(hipSetDevice(p->device));
-    if (!p->d_vwork) {
-        BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_vwork), invit_work_doubles(n, h.k) * sizeof(double)));
-        BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_vec), (size_t)n * sizeof(double)));
-        BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_chan), sizeof(int)));
-        BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_Esel), sizeof(double)));
+    if (l == p->pre_l && n0 == p->pre_n0) {                  // computed beside the bisection of the last solve
+        BSP_HIP(hipMemcpy(c, p->d_pvec, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        return BSP_OK;
     }
+    int rcs;
+    if ((rcs = ensure_vec_scratch(p))) return rcs;
     const int ch = l - p->last_l0;
     BSP_HIP(hipMemcpyAsync(p->d_chan, &ch, sizeof(int), hipMemcpyHostToDevice, p->st));
     BSP_HIP(hipMemcpyAsync(p->d_Esel, p->d_E + (size_t)ch * n + (n0 - 1), sizeof(double), hipMemcpyDeviceToDevice, p->st));

@@ -100,6 +100,7 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
 // tridiag.hip
 int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_e, double *d_w,
                   long ldw, hipStream_t st);
+int launch_bisect_one(int n, const double *d_d, const double *d_e, int m, double *d_out, hipStream_t st);
 // eigvec.hip
 // vector iv: channel chan[iv] of HB (HB + chan*k*n), eigenvalue E[iv]; work: nvec*invit_work_doubles
 int launch_inverse_iteration(int n, int k, int nvec, const double *d_SB, const double *d_HB,

@@ -239,6 +239,93 @@ __global__ __launch_bounds__(256) void bisect2_kernel(int n, int ldn, const doub
     }
 }
 
+// One eigenvalue (index m, 0-based, ascending) of one tridiagonal matrix by MULTISECTION on one wavefront: every round
+// the 64 lanes count at 64 interior points of the bracket, which shrinks 65-fold (about ten rounds instead of 56
+// bisections).  Used to start the inverse iteration for the eigenvector the reference consumes (Hij(:, n0_ini) of
+// channel l_ini, matrices.f90:267) while the batched bisection of all channels is still running.
+__global__ __launch_bounds__(64) void bisect_one_kernel(int n, const double *__restrict__ dg, const double *__restrict__ eg,
+                                                       int m, double *out)
+{
+    extern __shared__ double sm[];
+    const int np = (n + RS - 1) / RS * RS;
+    double *d = sm, *e2 = sm + np + RS;
+    const int lane = threadIdx.x;
+    double gl = 1e300, gu = -1e300;
+    for (int i = lane; i < n; i += 64) {
+        const double di = dg[i];
+        const double el = (i > 0) ? fabs(eg[i - 1]) : 0.0;
+        const double er = (i < n - 1) ? fabs(eg[i]) : 0.0;
+        gl = fmin(gl, di - el - er);
+        gu = fmax(gu, di + el + er);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        gl = fmin(gl, __shfl_xor(gl, off));
+        gu = fmax(gu, __shfl_xor(gu, off));
+    }
+    const double eps = 2.220446049250313e-16;
+    double tnorm = fmax(fabs(gl), fabs(gu));
+    if (!(tnorm > 0.0)) tnorm = 1.0;
+    int kexp;
+    (void)frexp(tnorm, &kexp);
+    const double sc = ldexp(1.0, -kexp), isc = ldexp(1.0, kexp);
+    for (int i = lane; i < np + RS; i += 64) {
+        d[i] = (i < n) ? dg[i] * sc : 2.0;
+        const double ev = (i < n - 1) ? (eg[i] * sc) : 0.0;
+        e2[i] = fmax(ev * ev, 1e-60);
+    }
+    __syncthreads();
+    double lo = gl * sc - 2.1 * eps * n - 1e-300, hi = gu * sc + 2.1 * eps * n + 1e-300;
+    for (int round = 0; round < 40; ++round) {
+        if (hi - lo <= 2.0 * eps * fmax(fabs(lo), fabs(hi)) + 1e-300) break;
+        const double w = (hi - lo) * (1.0 / 65.0);
+        const double x = lo + (lane + 1) * w;
+        if (!(x > lo && x < hi)) {                         // the bracket cannot be divided any further
+            const double mid = 0.5 * (lo + hi);
+            if (!(mid > lo && mid < hi)) break;
+        }
+        double p0 = 1.0, p1 = d[0] - x;
+        int cnt = (p1 < 0.0) ? 1 : 0;
+        for (int ib = 0; ib < np; ib += RS) {
+#pragma unroll
+            for (int r = 0; r < RS; ++r) {
+                const int i = ib + r + 1;
+                const double pn = __builtin_fma(d[i] - x, p1, -(e2[i - 1] * p0));
+                cnt += (int)((unsigned)(__double2hiint(pn) ^ __double2hiint(p1)) >> 31);
+                p0 = p1; p1 = pn;
+            }
+            int ea, eb;
+            (void)frexp(p1, &ea);
+            (void)frexp(p0, &eb);
+            const int ex = (p1 == 0.0) ? eb : ((p0 == 0.0) ? ea : max(ea, eb));
+            p1 = ldexp(p1, -ex); p0 = ldexp(p0, -ex);
+        }
+        // eigenvalue m lies left of the first point whose count exceeds m
+        const unsigned long long above = __ballot(cnt > m);
+        const int f = above ? (__ffsll((long long)above) - 1) : 64;
+        const double xl = __shfl(x, f > 0 ? f - 1 : 0), xh = __shfl(x, f < 64 ? f : 63);
+        const double nlo = (f > 0) ? xl : lo, nhi = (f < 64) ? xh : hi;
+        if (!(nhi - nlo < hi - lo)) break;
+        lo = nlo; hi = nhi;
+    }
+    if (lane == 0) *out = 0.5 * (lo + hi) * isc;
+}
+
+int launch_bisect_one(int n, const double *d_d, const double *d_e, int m, double *d_out, hipStream_t st)
+{
+    const size_t lds = (size_t)2 * (n + 3 * RS) * sizeof(double);
+    if (lds > 150 * 1024) return BSP_ERR_UNSUPPORTED;
+    static bool attr = false;
+    if (!attr) {
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect_one_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(bisect_one_kernel, dim3(1), dim3(64), lds, st, n, d_d, d_e, m, d_out);
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
+
 int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_e, double *d_w, long ldw,
                   hipStream_t st)
 {
