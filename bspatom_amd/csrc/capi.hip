@@ -246,7 +246,7 @@ extern "C" int bspatom_assemble(bspatom_problem *p, int l0, int nl, double *SB, 
 
 namespace bsp {
 int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const double *d_HB, const PipeBufs &b,
-                     double *d_Eout, hipStream_t st, hipEvent_t *ev)
+                     double *d_Eout, hipStream_t st, hipEvent_t *ev, bool with_bisect)
 {
     int rc;
     if ((rc = launch_band_cholesky(n, k, d_SB, b.UB, b.rdiag, b.info, st))) return rc;
@@ -259,6 +259,7 @@ int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const d
     if (ev) BSP_HIP(hipEventRecord(ev[2], st));
     if ((rc = launch_sb2st(n, npad, 64, nl, b.AB, b.d, b.e, st, b.status, b.sbctl))) return rc;
     if (ev) BSP_HIP(hipEventRecord(ev[3], st));
+    if (!with_bisect) return BSP_OK;                       // the caller enqueues other work first (see solve_impl)
     if ((rc = launch_bisect(n, npad, nl, b.d, b.e, d_Eout, n, st))) return rc;
     if (ev) BSP_HIP(hipEventRecord(ev[4], st));
     return BSP_OK;
@@ -290,7 +291,7 @@ static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, dou
     BSP_HIP(hipEventRecord(p->ev[1], p->st));
     PipeBufs pb{p->d_UB, p->d_rdiag, p->d_Y, p->d_C, p->d_AB, p->d_d, p->d_e, p->d_work, p->d_info, p->d_status, p->d_sbctl};
     double *Eout = E_dev_out ? E_dev_out : p->d_E;
-    if ((rc = pipeline_enqueue(n, np, h.k, nl, p->d_SB, p->d_HB, pb, Eout, p->st, &p->ev[1]))) return rc;
+    if ((rc = pipeline_enqueue(n, np, h.k, nl, p->d_SB, p->d_HB, pb, Eout, p->st, &p->ev[1], false))) return rc;
     // The consumed eigenvector (l_ini, n0_ini): its eigenvalue alone by multisection as soon as the tridiagonal
     // matrices exist (ev[4] = after sb2st), then the inverse iteration, on a second stream beside the batched bisection.
     p->pre_l = -1;
@@ -313,9 +314,13 @@ static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, dou
         if ((rc = launch_inverse_iteration(n, h.k, 1, p->d_SB, p->d_HB, p->d_chan, p->d_pE, p->d_vwork, p->d_pvec,
                                            p->d_pinfo, p->st2))) return rc;
         BSP_HIP(hipEventRecord(p->evx, p->st2));
-        BSP_HIP(hipStreamWaitEvent(p->st, p->evx, 0));
         p->pre_l = tl; p->pre_n0 = tn0;
     }
+    // the batched bisection is enqueued AFTER the one-wave kernels above: its 512 workgroups fill every CU's LDS
+    // for the whole 40 ms, a kernel that arrives later waits that long for a slot
+    if ((rc = launch_bisect(n, np, nl, p->d_d, p->d_e, Eout, n, p->st))) return rc;
+    BSP_HIP(hipEventRecord(p->ev[5], p->st));
+    if (p->pre_l >= 0) BSP_HIP(hipStreamWaitEvent(p->st, p->evx, 0));
     if (E_dev_out)   // keep a copy for bspatom_eigvec
         BSP_HIP(hipMemcpyAsync(p->d_E, E_dev_out, (size_t)nl * n * sizeof(double), hipMemcpyDeviceToDevice, p->st));
     BSP_HIP(hipStreamSynchronize(p->st));

@@ -122,6 +122,6 @@ struct PipeBufs {
 };
 size_t pipe_bytes_per_channel(int npad);
 int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const double *d_HB,
-                     const PipeBufs &b, double *d_Eout, hipStream_t st, hipEvent_t *ev);
+                     const PipeBufs &b, double *d_Eout, hipStream_t st, hipEvent_t *ev, bool with_bisect = true);
 
 }  // namespace bsp
