@@ -1,16 +1,20 @@
 // sb2st.hip -- stage 2 of the two-stage tridiagonalisation: band (half-width b = 64) -> tridiagonal
 // by Householder bulge chasing.  Replaces the second half of LAPACK DSYTRD (reference call
-// matrices.f90:248 -> DSYGV).  One workgroup (256 threads) per l-channel; the channels of a
-// batch run concurrently on different CUs.
+// matrices.f90:248 -> DSYGV).
 //
 // Band storage (lower, LD = 2b rows so that the bulge fits): AB[d + j*LD] = A(j+d, j), d < 2b.
 //
 // Sweep s annihilates column s below the sub-diagonal (reflector of length L <= b acting on rows
 // r0 = s+1 .. s+L, two-sided on the diagonal block), then chases the bulge down the band: each
-// chase step right-applies the current reflector to the L2 x L block B below the diagonal block
+// chase step ("item") right-applies the current reflector to the L2 x L block B below the diagonal block
 // (fill-in), annihilates B's first column with a new reflector, left-applies it to the rest of
-// B, and applies it two-sided to the next diagonal block D2.  B and D2 (64x64 doubles each) are
-// staged in LDS; vectors and partial sums live in LDS as well.
+// B, and applies it two-sided to the next diagonal block D2.
+//
+// Kernel generations kept here (BSP_SB2ST_VERSION; history and measurements in DESIGN.md 4.1):
+//   3  one workgroup per channel, register-blocked tiles, tiles through HBM every item
+//   6  two workgroups (two CUs of one XCD) per channel, sweep s+1 following sweep s through L2
+//   7  one 512-thread workgroup per channel running TWO sweeps per pass with on-chip forwarding
+//   8  (default) 7 paired as in 6: four sweeps in flight per channel
 #include <vector>
 #include "common.h"
 
@@ -18,182 +22,6 @@ namespace bsp {
 
 constexpr int SB = 64;             // band half-width handled by this kernel
 constexpr int TLD = SB + 1;        // LDS tile row stride (bank-conflict padding)
-
-struct HouseOut { double beta, tau; };
-
-// LAPACK dlarfg on x[0..L) held in LDS (vector overwritten by v, v[0] = 1).  All 256 threads call;
-// wave 0 does the work.  sh[0..1] scratch.  Entries whose squares underflow are dropped (tau = 0).
-__device__ static HouseOut house_lds(double *x, int L, double *sh, int tid)
-{
-    if (tid < 64) {
-        double xi = (tid < L) ? x[tid] : 0.0;
-        double sq = (tid >= 1) ? xi * xi : 0.0;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
-        const double alpha = __shfl(xi, 0);
-        double beta, tau, scale;
-        if (!(alpha * alpha + sq > 1e-280) || sq == 0.0) { beta = alpha; tau = 0.0; scale = 0.0; }
-        else {
-            const double nrm = sqrt(alpha * alpha + sq);
-            beta = (alpha >= 0.0) ? -nrm : nrm;
-            tau = (beta - alpha) / beta;
-            scale = 1.0 / (alpha - beta);
-        }
-        if (tid < L) x[tid] = (tid == 0) ? 1.0 : xi * scale;
-        else x[tid] = 0.0;
-        if (tid == 0) { sh[0] = beta; sh[1] = tau; }
-    }
-    __syncthreads();
-    HouseOut o; o.beta = sh[0]; o.tau = sh[1];
-    __syncthreads();
-    return o;
-}
-
-// Two-sided update D <- H D H, H = I - tau v v^T, on the L x L symmetric tile Dt (full storage):
-// p = tau D v ; alpha = -1/2 tau p^T v ; p += alpha v ; D -= v p^T + p v^T.
-__device__ static void two_sided(double (*Dt)[TLD], int L, const double *v, double tau, double *p,
-                                 double (*red)[SB], double *sh, int tid)
-{
-    const int i = tid & 63, part = tid >> 6;
-    double s = 0.0;
-    if (i < L)
-        for (int j = part * 16; j < part * 16 + 16; ++j) s += Dt[j][i] * v[j];   // D symmetric: column i
-    red[part][i] = s;
-    __syncthreads();
-    if (tid < 64) {
-        double pi = tau * (red[0][i] + red[1][i] + red[2][i] + red[3][i]);
-        double dot = (i < L) ? pi * v[i] : 0.0;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) dot += __shfl_xor(dot, off);
-        const double alpha = -0.5 * tau * dot;
-        p[i] = (i < L) ? pi + alpha * v[i] : 0.0;
-    }
-    __syncthreads();
-    if (i < L) {
-        const double vi = v[i], pi = p[i];
-        for (int j = part * 16; j < part * 16 + 16; ++j)
-            if (j < L) Dt[j][i] -= v[j] * pi + p[j] * vi;
-    }
-    __syncthreads();
-    (void)sh;
-}
-
-__global__ __launch_bounds__(256) void sb2st_kernel(int n, int npad, double *ABall, double *dall, double *eall)
-{
-    __shared__ double Bt[SB][TLD];      // Bt[j][i] = B(i, j)  (column j contiguous in i)
-    __shared__ double Dt[SB][TLD];      // Dt[j][i] = D(i, j)
-    __shared__ double v[SB], v2[SB], w[SB];
-    __shared__ double red[4][SB];
-    __shared__ double sh[4];
-    constexpr int LD = 2 * SB;
-    const int tid = threadIdx.x, i = tid & 63, part = tid >> 6;
-    const size_t ch = blockIdx.x;
-    double *AB = ABall + ch * ab_stride(npad);
-
-    for (int s = 0; s < n - 2; ++s) {
-        int L = (n - 1 - s < SB) ? (n - 1 - s) : SB;
-        if (L < 2) break;
-        int r0 = s + 1;
-        // ---- start of sweep: reflector from column s, rows r0 .. r0+L-1 (d = 1..L) ----
-        if (tid < 64) v[tid] = (tid < L) ? AB[(size_t)s * LD + 1 + tid] : 0.0;
-        __syncthreads();
-        HouseOut h = house_lds(v, L, sh, tid);
-        double tau = h.tau;
-        if (tid < L) AB[(size_t)s * LD + 1 + tid] = (tid == 0) ? h.beta : 0.0;
-        // diagonal block D = A[r0:r0+L, r0:r0+L]: D(i,j) (i>=j) = AB[(i-j) + (r0+j)*LD]
-        for (int j = part; j < SB; j += 4) {
-            double val = 0.0;
-            if (i < L && j < L && i >= j) val = AB[(size_t)(r0 + j) * LD + (i - j)];
-            Dt[j][i] = val;
-        }
-        __syncthreads();
-        for (int j = part; j < SB; j += 4)
-            if (i < j && j < L) Dt[j][i] = Dt[i][j];            // mirror: D(i,j) = D(j,i) for i<j
-        __syncthreads();
-        two_sided(Dt, L, v, tau, w, red, sh, tid);
-        for (int j = part; j < L; j += 4)
-            if (i < L && i >= j) AB[(size_t)(r0 + j) * LD + (i - j)] = Dt[j][i];
-        __syncthreads();
-        // ---- chase ----
-        double *vc = v, *vn = v2;
-        while (r0 + L < n) {
-            const int L2 = (n - (r0 + L) < SB) ? (n - (r0 + L)) : SB;
-            // B(i,j) = A(r0+L+i, r0+j) = AB[(L+i-j) + (r0+j)*LD], i < L2, j < L
-            for (int j = part; j < SB; j += 4) {
-                double val = 0.0;
-                if (i < L2 && j < L) val = AB[(size_t)(r0 + j) * LD + (L + i - j)];
-                Bt[j][i] = val;
-            }
-            __syncthreads();
-            // w = B vc ; B -= tau w vc^T
-            {
-                double sacc = 0.0;
-                for (int j = part * 16; j < part * 16 + 16; ++j) sacc += Bt[j][i] * vc[j];
-                red[part][i] = sacc;
-            }
-            __syncthreads();
-            if (tid < 64) w[i] = tau * (red[0][i] + red[1][i] + red[2][i] + red[3][i]);
-            __syncthreads();
-            {
-                const double wi = w[i];
-                for (int j = part * 16; j < part * 16 + 16; ++j) Bt[j][i] -= wi * vc[j];
-            }
-            __syncthreads();
-            // new reflector from B(:,0)
-            if (tid < 64) vn[tid] = (tid < L2) ? Bt[0][tid] : 0.0;
-            __syncthreads();
-            HouseOut h2 = house_lds(vn, L2, sh, tid);
-            const double tau2 = h2.tau;
-            if (tid < 64) Bt[0][tid] = (tid == 0) ? h2.beta : 0.0;
-            __syncthreads();
-            // z = vn^T B(:,1:) ; B(:,1:) -= tau2 vn z^T      (thread: column j = i, rows split in 4 parts)
-            {
-                const int j = i;
-                double sacc = 0.0;
-                if (j >= 1)
-                    for (int ii = part * 16; ii < part * 16 + 16; ++ii) sacc += vn[ii] * Bt[j][ii];
-                red[part][j] = sacc;
-            }
-            __syncthreads();
-            if (tid < 64) w[i] = tau2 * (red[0][i] + red[1][i] + red[2][i] + red[3][i]);
-            __syncthreads();
-            {
-                const int j = i;
-                if (j >= 1) {
-                    const double zj = w[j];
-                    for (int ii = part * 16; ii < part * 16 + 16; ++ii) Bt[j][ii] -= vn[ii] * zj;
-                }
-            }
-            __syncthreads();
-            for (int j = part; j < L; j += 4)
-                if (i < L2) AB[(size_t)(r0 + j) * LD + (L + i - j)] = Bt[j][i];
-            // next diagonal block D2 = A[r0+L : r0+L+L2, same]
-            const int rn = r0 + L;
-            for (int j = part; j < SB; j += 4) {
-                double val = 0.0;
-                if (i < L2 && j < L2 && i >= j) val = AB[(size_t)(rn + j) * LD + (i - j)];
-                Dt[j][i] = val;
-            }
-            __syncthreads();
-            for (int j = part; j < SB; j += 4)
-                if (i < j && j < L2) Dt[j][i] = Dt[i][j];
-            __syncthreads();
-            two_sided(Dt, L2, vn, tau2, w, red, sh, tid);
-            for (int j = part; j < L2; j += 4)
-                if (i < L2 && i >= j) AB[(size_t)(rn + j) * LD + (i - j)] = Dt[j][i];
-            __syncthreads();
-            r0 = rn; L = L2; tau = tau2;
-            double *tswap = vc; vc = vn; vn = tswap;
-        }
-    }
-    __syncthreads();
-    double *d = dall + ch * (size_t)npad, *e = eall + ch * (size_t)npad;
-    for (int j = tid; j < n; j += 256) {
-        d[j] = AB[(size_t)j * LD];
-        e[j] = (j < n - 1) ? AB[(size_t)j * LD + 1] : 0.0;
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // v2: same algorithm, restructured for latency.  Per chase step (5 workgroup barriers):
@@ -255,173 +83,6 @@ __device__ __forceinline__ double wave_house(double xi, int lane, int L, double 
     }
     return (lane == 0) ? 1.0 : ((lane < L) ? xi * scale : 0.0);
 }
-
-// dbg (timing experiments only, results are wrong when set): bit0 = no prefetch loads, bit1 = no chase stores
-__global__ __launch_bounds__(256) void sb2st_kernel_v2(int n, int npad, double *ABall, double *dall, double *eall, int dbg)
-{
-    __shared__ double Bt[SB][TLD];      // Bt[j][i] = B(i, j)
-    __shared__ double Dt[SB][TLD];      // Dt[j][i] = D2(i, j) for i >= j (lower triangle only)
-    __shared__ double va[SB], vb[SB], w[SB], z[SB], pv[SB];
-    __shared__ double red[4][SB], red2[4][SB];
-    __shared__ double sc[8];
-    constexpr int LD = 2 * SB;
-    const int tid = threadIdx.x, i = tid & 63, part = tid >> 6;
-    const size_t ch = blockIdx.x;
-    double *AB = ABall + ch * ab_stride(npad);
-
-    for (int s = 0; s < n - 2; ++s) {
-        int L = (n - 1 - s < SB) ? (n - 1 - s) : SB;
-        if (L < 2) break;
-        int r0 = s + 1;
-        double *vc = va, *vn = vb;
-        __syncthreads();          // HBM stores of the previous sweep are visible to every wave
-        // ---- sweep start: reflector from column s; two-sided update of D = A[r0:r0+L, r0:r0+L] ----
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int j = part + 4 * q;
-            const bool ok = (i < L && j < L && i >= j);
-            const double val = AB[ok ? ((size_t)(r0 + j) * LD + (i - j)) : 0];     // unconditional load, clamped address
-            Dt[j][i] = ok ? val : 0.0;
-        }
-        double tau;
-        if (tid < 64) {
-            const double xraw = AB[(tid < L) ? ((size_t)s * LD + 1 + tid) : 0];
-            const double xi = (tid < L) ? xraw : 0.0;
-            double beta;
-            const double vi = wave_house(xi, tid, L, &beta, &tau);
-            vc[tid] = vi;
-            if (tid < L) AB[(size_t)s * LD + 1 + tid] = (tid == 0) ? beta : 0.0;
-            if (tid == 0) sc[0] = tau;
-        }
-        lds_barrier();
-        tau = sc[0];
-        {   // p0 = D vc (partials), D symmetric from its lower triangle
-            double sacc = 0.0;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int x = part * 16 + q;
-                sacc += ((x <= i) ? Dt[x][i] : Dt[i][x]) * vc[x];
-            }
-            red[part][i] = sacc;
-        }
-        lds_barrier();
-        if (tid < 64) {
-            double pi = tau * (red[0][i] + red[1][i] + red[2][i] + red[3][i]);
-            const double dot = wave_sum(pi * vc[i]);
-            pv[i] = pi + (-0.5 * tau * dot) * vc[i];
-        }
-        lds_barrier();
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int j = part + 4 * q;
-            if (i < L && j < L && i >= j)
-                AB[(size_t)(r0 + j) * LD + (i - j)] = Dt[j][i] - (vc[i] * pv[j] + pv[i] * vc[j]);
-        }
-        bool have = (r0 + L < n);
-        int L2 = have ? ((n - (r0 + L) < SB) ? (n - (r0 + L)) : SB) : 0;
-        lds_barrier();             // all reads of Dt done before it is overwritten
-        if (have) {                // first chase step's tiles (not touched by the update above)
-            const int rn = r0 + L;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int j = part + 4 * q;
-                const bool okb = (i < L2 && j < L), okd = (i < L2 && j < L2 && i >= j);
-                const double bv = AB[okb ? ((size_t)(r0 + j) * LD + (L + i - j)) : 0];
-                const double dv = AB[okd ? ((size_t)(rn + j) * LD + (i - j)) : 0];
-                Bt[j][i] = okb ? bv : 0.0; Dt[j][i] = okd ? dv : 0.0;
-            }
-        }
-        lds_barrier();
-        // ---- chase ----
-        while (have) {
-            const int rn = r0 + L;
-            const bool have_next = (rn + L2 < n);
-            const int L3 = have_next ? ((n - (rn + L2) < SB) ? (n - (rn + L2)) : SB) : 0;
-            // A: prefetch next tiles into registers; partial w0 = B vc
-            // (L3 = 0 on the last step: every address clamps to AB[0], every value is discarded)
-            double pb[16], pd[16];
-            {
-                const int rnn = rn + L2;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int j = part + 4 * q;
-                    const bool okb = (i < L3 && j < L2), okd = (i < L3 && j < L3 && i >= j);
-                    if (dbg & 1) { pb[q] = 1e-3 * (i + j); pd[q] = 1e-3 * (i - j) + (i == j ? 1.0 : 0.0); continue; }
-                    pb[q] = AB[okb ? ((size_t)(rn + j) * LD + (L2 + i - j)) : 0];
-                    pd[q] = AB[okd ? ((size_t)(rnn + j) * LD + (i - j)) : 0];
-                }
-            }
-            {
-                double sacc = 0.0;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) { const int j = part * 16 + q; sacc += Bt[j][i] * vc[j]; }
-                red[part][i] = sacc;
-            }
-            lds_barrier();
-            // B: wave 0 builds the new reflector
-            if (tid < 64) {
-                const double wi = tau * (red[0][i] + red[1][i] + red[2][i] + red[3][i]);
-                const double xi = (i < L2) ? (Bt[0][i] - wi * vc[0]) : 0.0;
-                double beta2, tau2;
-                const double vi = wave_house(xi, i, L2, &beta2, &tau2);
-                const double sdot = wave_sum(vi * wi);
-                w[i] = wi; vn[i] = vi;
-                if (i == 0) { sc[1] = beta2; sc[2] = tau2; sc[3] = sdot; }
-            }
-            lds_barrier();
-            const double beta2 = sc[1], tau2 = sc[2], sdot = sc[3];
-            // C: partial z0 = vn^T B (thread: column j = i, rows of this part) ; partial p0 = D2 vn
-            {
-                double zacc = 0.0, pacc = 0.0;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int x = part * 16 + q;
-                    zacc += vn[x] * Bt[i][x];                                   // column i of B, rows x
-                    pacc += ((x <= i) ? Dt[x][i] : Dt[i][x]) * vn[x];           // row i of symmetric D2
-                }
-                red[part][i] = zacc; red2[part][i] = pacc;
-            }
-            lds_barrier();
-            // D: wave 0 -> z, wave 1 -> p
-            if (tid < 64) {
-                z[i] = tau2 * ((red[0][i] + red[1][i] + red[2][i] + red[3][i]) - sdot * vc[i]);
-            } else if (tid < 128) {
-                double pi = tau2 * (red2[0][i] + red2[1][i] + red2[2][i] + red2[3][i]);
-                const double dot = wave_sum(pi * vn[i]);
-                pv[i] = pi + (-0.5 * tau2 * dot) * vn[i];
-            }
-            lds_barrier();
-            // E: updates, stores, and hand-over to the prefetched tiles
-            {
-                const double wi = w[i], vni = vn[i], pi = pv[i];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int j = part + 4 * q;
-                    double bnew = Bt[j][i] - (wi * vc[j] + vni * z[j]);
-                    if (j == 0) bnew = (i == 0) ? beta2 : 0.0;
-                    const bool st_ok = !(dbg & 2);
-                    if (st_ok && i < L2 && j < L) AB[(size_t)(r0 + j) * LD + (L + i - j)] = bnew;
-                    if (st_ok && i < L2 && j < L2 && i >= j)
-                        AB[(size_t)(rn + j) * LD + (i - j)] = Dt[j][i] - (vni * pv[j] + pi * vn[j]);
-                    {
-                        const bool okb = (i < L3 && j < L2), okd = (i < L3 && j < L3 && i >= j);
-                        Bt[j][i] = okb ? pb[q] : 0.0; Dt[j][i] = okd ? pd[q] : 0.0;
-                    }
-                }
-            }
-            lds_barrier();
-            r0 = rn; L = L2; L2 = L3; tau = tau2; have = have_next;
-            double *tswap = vc; vc = vn; vn = tswap;
-        }
-    }
-    __syncthreads();
-    double *d = dall + ch * (size_t)npad, *e = eall + ch * (size_t)npad;
-    for (int j = tid; j < n; j += 256) {
-        d[j] = AB[(size_t)j * LD];
-        e[j] = (j < n - 1) ? AB[(size_t)j * LD + 1] : 0.0;
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // v3: register-blocked tiles.  Thread (bi, bj) of the 16 x 16 thread grid owns the 4 x 4 sub-blocks
@@ -772,254 +433,8 @@ __global__ __launch_bounds__(256) void sb2st_kernel_v3(int n, int npad, double *
     sb2st_v3_body<DIAG>(n, npad, ABall, dall, eall, diag, blockIdx.x);
 }
 
-// ------------------------------------------------------------------------------------------------
-// v4: TWO SWEEPS IN FLIGHT per workgroup.  512 threads = two halves of 4 wavefronts; half h works on
-// sweeps s = h, h+2, h+4, ... with the v3 step (register tiles, 4 phases), both halves on the SAME
-// barriers, so the serial reflector phases and the load/store issue of one half overlap with the
-// other half on the CU's four SIMDs.  Sweep s+1 may touch an item only when sweep s is LAG items
-// past it (region overlap is 1 item, its prefetch 1 more, store completion 3 more).
-// Everything inside a super-step is branch-free and mask-driven (no control flow around loads):
-//   PRELOAD : nothing computed; the "prefetch" fetches the sweep's first diagonal block (B masked to 0)
-//   ITEM0   : the sweep start = a chase item with an empty B tile whose reflector comes from column s
-//   CHASE   : as v3
-//   IDLE    : all masks off (waiting for the other half, or finished)
-constexpr int SB4_LAG = 6;
+// what a half does in one super-step (v6, v7)
 enum { ACT_IDLE = 0, ACT_PRELOAD = 1, ACT_ITEM0 = 2, ACT_CHASE = 3 };
-
-struct Sb4Shared {
-    Sb3Lds S[2];
-    int sweep[2], done[2], fin[2], viol;
-};
-
-template <int PAR>
-__device__ __forceinline__ void superstep_v4(double *__restrict__ AB, Sb4Shared &SH, int h, int htid, int ib, int j0,
-                                             const unsigned (&off)[4][4], unsigned low, int n,
-                                             int &state, int &sw, ChaseState &st, double &xpre,
-                                             double (&Bc)[4][4], double (&Dc)[4][4], double (&Bn)[4][4], double (&Dn)[4][4])
-{
-    constexpr int LD = 2 * SB;
-    Sb3Lds &S = SH.S[h];
-    const double *vc = PAR ? S.vb : S.va;
-    double *vn = PAR ? S.va : S.vb;
-    const int jb = j0 >> 2;
-    lds_barrier();                                           // barrier 0: progress of both halves is published
-    // ---- decide (identical in every thread of the half) ----
-    int act = ACT_IDLE;
-    {
-        const int o = h ^ 1;
-        const int osw = SH.sweep[o], odn = SH.done[o], ofin = SH.fin[o];
-        if (state == 1) {                                    // NEED_PRELOAD: may item 0 of sweep sw start?
-            const bool ok = (sw == 0) || ofin || (osw > sw - 1) || (osw == sw - 1 && odn >= SB4_LAG);
-            act = ok ? ACT_PRELOAD : ACT_IDLE;
-        } else if (state == 2) act = ACT_ITEM0;
-        else if (state == 3) act = ACT_CHASE;
-        if (act >= ACT_ITEM0 && sw > 0 && !ofin && !(osw > sw - 1)) {
-            const int k = (act == ACT_ITEM0) ? 0 : SH.done[h];
-            if (!(osw == sw - 1 && odn >= k + SB4_LAG - 1) && htid == 0) atomicAdd(&SH.viol, 1);   // must not happen
-        }
-    }
-    const bool all_fin = SH.fin[0] && SH.fin[1];
-    if (all_fin) { state = -1; return; }
-    const bool comp = (act >= ACT_ITEM0);
-    const bool item0 = (act == ACT_ITEM0);
-    const int L0 = (n - 1 - sw < SB) ? (n - 1 - sw) : SB;   // first block size of sweep sw
-    if (item0) { st.r0 = sw + 1; st.L = 0; st.L2 = L0; st.tau = 0.0; }
-    const int r0 = comp ? st.r0 : 0, L = comp ? st.L : 0, L2 = comp ? st.L2 : 0, rn = r0 + L;
-    // what to prefetch: PRELOAD -> tiles of item 0 (B empty, D2 at sw+1); ITEM0/CHASE -> the next chase item
-    int pr0, pL, pL2;
-    bool have_pf;
-    if (act == ACT_PRELOAD) { pr0 = sw + 1; pL = 0; pL2 = L0; have_pf = true; }
-    else {
-        have_pf = comp && (rn + L2 < n);
-        pr0 = rn; pL = L2; pL2 = have_pf ? ((n - (rn + L2) < SB) ? (n - (rn + L2)) : SB) : 0;
-    }
-    // ---- P1 ----
-    {
-        const double *__restrict__ Bb = have_pf ? (AB + ((size_t)pr0 * LD + pL)) : AB;
-        const double *__restrict__ Db = have_pf ? (AB + (size_t)(pr0 + pL) * LD) : AB;
-#pragma unroll
-        for (int cj = 0; cj < 4; ++cj)
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri) {
-                const int i = SB3_ROW(ri), j = SB3_COL(cj);
-                const bool okb = have_pf && (i < pL2) && (j < pL);
-                const bool okd = have_pf && ((low >> (ri * 4 + cj)) & 1u) && (i < pL2);
-                const double bv = Bb[okb ? off[ri][cj] : 0u];
-                const double dv = Db[okd ? off[ri][cj] : 0u];
-                Bn[ri][cj] = okb ? bv : 0.0;
-                Dn[ri][cj] = okd ? dv : 0.0;
-            }
-        // column sw of the band (the sweep's first reflector), fetched by wave 0 of the half during PRELOAD
-        if (htid < 64) {
-            const bool okx = (act == ACT_PRELOAD) && (htid < L0);
-            const double xr = AB[okx ? ((size_t)sw * LD + 1 + htid) : 0];
-            xpre = (act == ACT_PRELOAD) ? (okx ? xr : 0.0) : xpre;
-        }
-        double vcj[4];
-#pragma unroll
-        for (int cj = 0; cj < 4; ++cj) vcj[cj] = vc[j0 + cj];
-#pragma unroll
-        for (int ri = 0; ri < 4; ++ri) {
-            double a = 0.0;
-#pragma unroll
-            for (int cj = 0; cj < 4; ++cj) a += Bc[ri][cj] * vcj[cj];
-            S.R1[jb][SB3_ROW(ri)] = a;
-        }
-        if (jb == 0) {
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri) S.x0[SB3_ROW(ri)] = Bc[ri][0];
-        }
-    }
-    lds_barrier();
-    // ---- P2: wave 0 of the half ----
-    if (htid < 64) {
-        const int i = htid;
-        double a = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) a += S.R1[q][i];
-        const double wi = item0 ? 0.0 : st.tau * a;
-        const double xc = item0 ? xpre : (S.x0[i] - wi * vc[0]);
-        const double xi = (i < L2) ? xc : 0.0;
-        double beta2, tau2;
-        const double vi = wave_house(xi, i, L2, &beta2, &tau2);
-        const double sdot = wave_sum(vi * wi);
-        S.w[i] = wi; vn[i] = vi;
-        if (i == 0) { S.sc[1] = beta2; S.sc[2] = tau2; S.sc[3] = sdot; }
-    }
-    lds_barrier();
-    const double beta2 = S.sc[1], tau2 = S.sc[2], sdot = S.sc[3];
-    // ---- P3 ----
-    double vni[4], vnj[4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x) { vni[x] = vn[SB3_ROW(x)]; vnj[x] = vn[j0 + x]; }
-    {
-#pragma unroll
-        for (int cj = 0; cj < 4; ++cj) {
-            double a = 0.0;
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri) a += vni[ri] * Bc[ri][cj];
-            S.R2[ib][j0 + cj] = a;
-        }
-#pragma unroll
-        for (int ri = 0; ri < 4; ++ri) {
-            double a = 0.0;
-#pragma unroll
-            for (int cj = 0; cj < 4; ++cj) a += Dc[ri][cj] * vnj[cj];
-            S.R3[jb][SB3_ROW(ri)] = a;
-        }
-#pragma unroll
-        for (int cj = 0; cj < 4; ++cj) {
-            double a = 0.0;
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri) a += (SB3_ROW(ri) != j0 + cj) ? Dc[ri][cj] * vni[ri] : 0.0;
-            S.R4[ib][j0 + cj] = a;
-        }
-    }
-    lds_barrier();
-    // ---- P4 ----
-    if (htid < 64) {
-        const int j = htid;
-        double a = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) a += S.R2[q][j];
-        S.z[j] = tau2 * (a - sdot * vc[j]);
-    } else if (htid < 128) {
-        const int i = htid - 64;
-        double a = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) a += S.R3[q][i] + S.R4[q][i];
-        const double pi = tau2 * a;
-        const double dot = wave_sum(pi * vn[i]);
-        S.pv[i] = pi + (-0.5 * tau2 * dot) * vn[i];
-    }
-    lds_barrier();
-    // ---- P5 ----
-    {
-        double wi[4], zj[4], vcj[4], pi[4], pj[4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            wi[x] = S.w[SB3_ROW(x)]; zj[x] = S.z[j0 + x]; vcj[x] = vc[j0 + x]; pi[x] = S.pv[SB3_ROW(x)]; pj[x] = S.pv[j0 + x];
-        }
-        double *__restrict__ Bb = AB + ((size_t)r0 * LD + L);
-        double *__restrict__ Db = AB + (size_t)rn * LD;
-#pragma unroll
-        for (int cj = 0; cj < 4; ++cj)
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri) {
-                const int i = SB3_ROW(ri), j = j0 + cj;
-                double bnew = Bc[ri][cj] - (wi[ri] * vcj[cj] + vni[ri] * zj[cj]);
-                if (j == 0) bnew = (i == 0) ? beta2 : 0.0;
-                if (i < L2 && j < L) Bb[off[ri][cj]] = bnew;
-                if (((low >> (ri * 4 + cj)) & 1u) && i < L2)
-                    Db[off[ri][cj]] = Dc[ri][cj] - (vni[ri] * pj[cj] + pi[ri] * vnj[cj]);
-            }
-        if (item0 && htid < L2) AB[(size_t)sw * LD + 1 + htid] = (htid == 0) ? beta2 : 0.0;
-    }
-    // ---- state update + publication (read by the other half after the next barrier 0) ----
-    if (act == ACT_PRELOAD) state = 2;
-    else if (comp) {
-        const bool more = (rn + L2 < n);
-        st.r0 = rn; st.L = L2; st.L2 = pL2; st.tau = tau2;
-        int dn = (act == ACT_ITEM0) ? 1 : (SH.done[h] + 1);
-        if (more) state = 3;
-        else {                                               // sweep finished
-            sw += 2; dn = 0;
-            const int Lnext = (n - 1 - sw < SB) ? (n - 1 - sw) : SB;
-            state = (sw < n - 2 && Lnext >= 2) ? 1 : 0;
-        }
-        if (htid == 0) { SH.sweep[h] = sw; SH.done[h] = dn; if (state == 0) SH.fin[h] = 1; }
-    }
-}
-
-__global__ __launch_bounds__(512) void sb2st_kernel_v4(int n, int npad, double *ABall, double *dall, double *eall,
-                                                      int *viol_out)
-{
-    __shared__ Sb4Shared SH;
-    constexpr int LD = 2 * SB;
-    const int tid = threadIdx.x, h = tid >> 8, htid = tid & 255, lane = tid & 63, hwave = htid >> 6;
-    const int ib = lane & 15, jb = (lane >> 4) + 4 * hwave;
-    const int j0 = 4 * jb;
-    unsigned off[4][4], low = 0;
-#pragma unroll
-    for (int cj = 0; cj < 4; ++cj)
-#pragma unroll
-        for (int ri = 0; ri < 4; ++ri) {
-            const int i = SB3_ROW(ri), j = j0 + cj;
-            off[ri][cj] = (unsigned)(j * (LD - 1) + i);
-            if (i >= j) low |= 1u << (ri * 4 + cj);
-        }
-    const size_t ch = blockIdx.x;
-    double *AB = ABall + ch * ab_stride(npad);
-    if (tid == 0) { SH.viol = 0; }
-    if (htid == 0) {
-        const int L0 = (n - 1 - h < SB) ? (n - 1 - h) : SB;
-        const bool any = (h < n - 2) && (L0 >= 2);
-        SH.sweep[h] = h; SH.done[h] = 0; SH.fin[h] = any ? 0 : 1;
-    }
-    __syncthreads();
-    int state = SH.fin[h] ? 0 : 1, sw = h;
-    ChaseState st; st.r0 = 0; st.L = 0; st.L2 = 0; st.L3 = 0; st.tau = 0.0;
-    double xpre = 0.0;
-    double B0[4][4], D0[4][4], B1[4][4], D1[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { B0[a][c] = 0.0; D0[a][c] = 0.0; B1[a][c] = 0.0; D1[a][c] = 0.0; }
-    for (;;) {
-        superstep_v4<0>(AB, SH, h, htid, ib, j0, off, low, n, state, sw, st, xpre, B0, D0, B1, D1);
-        if (state < 0) break;
-        superstep_v4<1>(AB, SH, h, htid, ib, j0, off, low, n, state, sw, st, xpre, B1, D1, B0, D0);
-        if (state < 0) break;
-    }
-    __syncthreads();
-    if (tid == 0 && SH.viol) atomicAdd(viol_out, SH.viol);
-    double *d = dall + ch * (size_t)npad, *e = eall + ch * (size_t)npad;
-    for (int j = tid; j < n; j += 512) {
-        d[j] = AB[(size_t)j * LD];
-        e[j] = (j < n - 1) ? AB[(size_t)j * LD + 1] : 0.0;
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // v6: TWO WORKGROUPS = TWO CUs PER CHANNEL.  v3 runs at the single-CU HBM rate (22 GB/s, 96 KB per
@@ -2151,8 +1566,11 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
     if (b != SB) return BSP_ERR_ARG;
     static int ver = -1;
     if (ver < 0) { const char *e = getenv("BSP_SB2ST_VERSION"); ver = e ? atoi(e) : 8; }
-    if (ver == 1) hipLaunchKernelGGL(sb2st_kernel, dim3(batch), dim3(256), 0, st, n, npad, d_AB, d_d, d_e);
-    else if (ver == 6) {
+    // 8 (default): paired two-sweep workgroups; 7: one two-sweep workgroup per channel; 6: paired one-sweep
+    // workgroups; 3: one one-sweep workgroup per channel (the generations DESIGN.md 4.1 describes; v1, v2, v4 are in
+    // the history only)
+    if (ver != 3 && ver != 6 && ver != 7 && ver != 8) return BSP_ERR_ARG;
+    if (ver == 6) {
         static Sb6Ctl *s_ctl = nullptr;
         static int cap = 0;
         Sb6Ctl *d_ctl = static_cast<Sb6Ctl *>(ctl);
@@ -2259,17 +1677,6 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
             if (hv) return BSP_ERR_HIP;
         }
     }
-    else if (ver == 4) {
-        static int *d_viol = nullptr;
-        if (!d_viol) { BSP_HIP(hipMalloc(reinterpret_cast<void **>(&d_viol), sizeof(int))); BSP_HIP(hipMemset(d_viol, 0, sizeof(int))); }
-        hipLaunchKernelGGL(sb2st_kernel_v4, dim3(batch), dim3(512), 0, st, n, npad, d_AB, d_d, d_e, d_viol);
-        if (getenv("BSP_SB2ST_CHECK")) {
-            int hv = 0;
-            BSP_HIP(hipStreamSynchronize(st));
-            BSP_HIP(hipMemcpy(&hv, d_viol, sizeof(int), hipMemcpyDeviceToHost));
-            if (hv) { fprintf(stderr, "bspatom: sb2st v4 dependency violations: %d\n", hv); return BSP_ERR_HIP; }
-        }
-    }
     else if (ver == 3) {
         static int diag = -1;
         if (diag < 0) { const char *e = getenv("BSP_SB2ST_DIAG"); diag = e ? atoi(e) : 0; }
@@ -2293,11 +1700,6 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
                 fprintf(stderr, "\n");
             }
         }
-    }
-    else {
-        static int dbg = -1;
-        if (dbg < 0) { const char *e = getenv("BSP_SB2ST_DBG"); dbg = e ? atoi(e) : 0; }
-        hipLaunchKernelGGL(sb2st_kernel_v2, dim3(batch), dim3(256), 0, st, n, npad, d_AB, d_d, d_e, dbg);
     }
     BSP_HIP(hipGetLastError());
     return BSP_OK;
