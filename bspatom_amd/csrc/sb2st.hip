@@ -820,11 +820,22 @@ struct Sb7Shared {
 // Two workgroups (two CUs of one XCD) per channel, as in v6: this workgroup runs sweeps first, first + 4, ...
 // (half A) and first + 1, first + 5, ... (half B); the partner runs the two sweeps in between.  Half A's
 // tiles then come from what the PARTNER's half B stored; `prog` carries B's progress across.
+// control block of one channel for v7/v8: a RING of P <= SB8_MAXP workgroups (P CUs of one XCD).  Member w runs the
+// sweeps 2w + 2P t (half A) and 2w + 1 + 2P t (half B); half A's tiles come from what member w-1's half B stored.
+constexpr int SB8_MAXP = 8;
+struct Sb8Ctl {
+    unsigned long long hs;                 // handshake: byte w = 0x10 | XCC id of member w; bit 62 COMMIT, bit 63 ABORT
+    int err, pad;
+    unsigned long long prog[SB8_MAXP];     // published half-B progress of member w: (sweep << 20) | items ; SB6_FIN at the end
+    unsigned long long nwait[2], wcycles[2];
+};
+constexpr unsigned long long SB8_COMMIT = 1ull << 62, SB8_ABORT = 1ull << 63;
+
 struct Pair7 {
     int paired, stride;
     const unsigned long long *pollp;   // partner's published B progress
     unsigned long long *pubp;          // this workgroup's
-    Sb6Ctl *C;
+    Sb8Ctl *C;
     int *status;
     int margin, hyst, lead;            // partner's published lead demanded before an item / extra once a wait began / extra at a sweep's start
 };
@@ -980,6 +991,7 @@ __device__ __forceinline__ void body_v7A(double *__restrict__ AB, Sb7Shared &SH,
     lds_barrier();
     SB7_STAMP(4);
     const double beta2 = S.sc[1], tau2 = S.sc[2], sdot = S.sc[3];
+    asm volatile("" : "+v"(htid), "+v"(ib), "+v"(j0), "+v"(o0), "+v"(low));   // re-derive per phase: see the top of the body
     // ---- P3 ----
     double vni[4], vnj[4];
 #pragma unroll
@@ -1045,6 +1057,7 @@ __device__ __forceinline__ void body_v7A(double *__restrict__ AB, Sb7Shared &SH,
     SB7_STAMP(7);
     lds_barrier();
     SB7_STAMP(8);
+    asm volatile("" : "+v"(htid), "+v"(ib), "+v"(j0), "+v"(o0), "+v"(low));   // re-derive per phase: see the top of the body
     // ---- P5: updated tiles -> exchange frames; only the finished entries go to HBM ----
     if (DIAG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SB7_STAMP(10); }
     if (comp) {
@@ -1161,7 +1174,8 @@ __device__ __forceinline__ void superstep_v7A(double *__restrict__ AB, Sb7Shared
             if (ok && pc.paired) {
                 // start a sweep with some slack behind the partner, so that timing jitter does not end in holds in
                 // mid-sweep; the slack must fit the ring (4 sweeps in flight over kb items each), hence the clamp
-                int lead = (kb - 18) / 2;
+                const int P = pc.stride / 2;
+                int lead = (kb - 9 * P) / P;
                 lead = lead < 0 ? 0 : (lead > pc.lead ? pc.lead : lead);
                 ok = sb6_dep_ok(sb7_rfl64(SH.pw), sw, pc.margin + lead);               // not yet: idle and poll again
             }
@@ -1282,6 +1296,7 @@ __device__ __forceinline__ void body_v7B(double *__restrict__ AB, Sb7Shared &SH,
     lds_barrier();
     SB7_STAMP(4);
     const double beta2 = S.sc[1], tau2 = S.sc[2], sdot = S.sc[3];
+    asm volatile("" : "+v"(htid), "+v"(ib), "+v"(j0), "+v"(o0), "+v"(low));   // re-derive per phase: see the top of the body
     // ---- P3 ----
     double vni[4], vnj[4];
 #pragma unroll
@@ -1331,6 +1346,7 @@ __device__ __forceinline__ void body_v7B(double *__restrict__ AB, Sb7Shared &SH,
     SB7_STAMP(7);
     lds_barrier();
     SB7_STAMP(8);
+    asm volatile("" : "+v"(htid), "+v"(ib), "+v"(j0), "+v"(o0), "+v"(low));   // re-derive per phase: see the top of the body
     // ---- P5: results to HBM ----
     if (pc.paired) {
         // the stores of the previous super-step are complete by now (the wait is free): what was pending becomes
@@ -1428,7 +1444,8 @@ __device__ __forceinline__ void superstep_v7B(double *__restrict__ AB, Sb7Shared
 
 template <int DIAG>
 __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, int batch, double *ABall, double *dall, double *eall,
-                                                       int *status, long long *diag, Sb6Ctl *ctl, int margin, int hyst, int lead)
+                                                       int *status, long long *diag, Sb8Ctl *ctl, int P, int margin, int hyst,
+                                                       int lead)
 {
     Diag7 dg;
     if (DIAG) { for (int q = 0; q < 12; ++q) dg.acc[q] = 0; dg.tlast = (long long)__builtin_amdgcn_s_memtime(); }
@@ -1436,44 +1453,45 @@ __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, int batc
     Sb7Shared &SH = *reinterpret_cast<Sb7Shared *>(sb7_raw);
     constexpr int LD = 2 * SB;
     const int tid = threadIdx.x, h = __builtin_amdgcn_readfirstlane(tid >> 8), htid = tid & 255, lane = tid & 63, hwave = htid >> 6;
-    // ---- which channel, alone or as one of a pair of workgroups (ctl != nullptr: v6's pairing) ----
+    // ---- which channel; alone (ctl == nullptr) or member w of a ring of P workgroups ----
     int chn = blockIdx.x, w = 0;
     Pair7 pc; pc.paired = 0; pc.stride = 2; pc.pollp = nullptr; pc.pubp = nullptr; pc.C = nullptr; pc.status = status;
     pc.margin = margin; pc.hyst = hyst; pc.lead = lead;
     if (ctl) {
-        // blocks b and b+8 are observed to share an XCD (round-robin dispatch): pair them, then VERIFY
-        const int blk = blockIdx.x, grp = blk >> 4, rr = blk & 15;
+        // blocks b, b+8, b+16, ... are observed to share an XCD (round-robin dispatch): they form a ring, then VERIFY
+        const int blk = blockIdx.x, grp = blk / (8 * P), rr = blk % (8 * P);
         chn = grp * 8 + (rr & 7); w = rr >> 3;
         if (chn >= batch) return;
-        Sb6Ctl *C = ctl + chn;
-        if (tid == 0) {                                       // handshake: 0 = exit, 1 = pair, 2 = alone
-            const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu;     // HW_REG_XCC_ID
-            const unsigned mine = (0x10u | xcc) << (8 * w);
-            const unsigned old = atomicOr(&C->pair, mine);
-            int mode = -1;
-            if (old & 0x80000000u) mode = 0;
-            for (int spin = 0; mode < 0 && spin < 400000; ++spin) {
-                const unsigned v = __hip_atomic_load(&C->pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (v & 0x80000000u) { mode = 0; break; }
-                const unsigned ob = (v >> (8 * (w ^ 1))) & 0xffu;
-                if (ob & 0x10u) { mode = ((ob & 0xfu) == xcc) ? 1 : (w == 0 ? 2 : 0); break; }
-                __builtin_amdgcn_s_sleep(4);
+        Sb8Ctl *C = ctl + chn;
+        if (tid == 0) {
+            // Handshake: 0 = exit, 1 = ring, 2 = alone.  Every member sets its byte; the one that completes the set
+            // COMMITs, one that has waited too long ABORTs; both by compare-and-swap on the same word, so exactly one
+            // of the two bits is ever set and every member (also one that arrives later) reads the same decision.
+            // After an ABORT, or if the members turn out not to share an XCD, member 0 runs the channel alone.
+            const unsigned long long xcc = (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu);   // HW_REG_XCC_ID
+            const unsigned long long mine = (0x10ull | xcc) << (8 * w);
+            unsigned long long full = 0;
+            for (int q = 0; q < P; ++q) full |= 0x10ull << (8 * q);
+            unsigned long long v = atomicOr(&C->hs, mine) | mine;
+            for (int spin = 0; !(v & (SB8_COMMIT | SB8_ABORT)); ++spin) {
+                if ((v & full) == full) atomicCAS(&C->hs, v, v | SB8_COMMIT);
+                else if (spin > 400000) atomicCAS(&C->hs, v, v | SB8_ABORT);
+                else __builtin_amdgcn_s_sleep(4);
+                v = __hip_atomic_load(&C->hs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (mode < 0) {                                   // partner did not show up: try to claim the channel
-                if (atomicCAS(&C->pair, mine, mine | 0x80000000u) == mine) mode = 2;
-                else {
-                    const unsigned v = __hip_atomic_load(&C->pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned ob = (v >> (8 * (w ^ 1))) & 0xffu;
-                    if (v & 0x80000000u) mode = 0;
-                    else mode = ((ob & 0x10u) && (ob & 0xfu) == xcc) ? 1 : (w == 0 ? 2 : 0);
-                }
+            int mode;
+            if (v & SB8_ABORT) mode = (w == 0) ? 2 : 0;
+            else {
+                bool same = true;
+                for (int q = 1; q < P; ++q) same = same && (((v >> (8 * q)) & 0xfu) == (v & 0xfu));
+                mode = same ? 1 : ((w == 0) ? 2 : 0);
             }
             SH.mode = mode;
         }
         __syncthreads();
         const int mode = __builtin_amdgcn_readfirstlane(SH.mode);
         if (mode == 0) return;
-        if (mode == 1) { pc.paired = 1; pc.stride = 4; pc.pollp = &C->prog[w ^ 1]; pc.pubp = &C->prog[w]; }
+        if (mode == 1 && P > 1) { pc.paired = 1; pc.stride = 2 * P; pc.pollp = &C->prog[(w + P - 1) % P]; pc.pubp = &C->prog[w]; }
         else w = 0;
         pc.C = C;
     }
@@ -1537,12 +1555,14 @@ __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, int batc
     if (pc.paired) {
         if (tid == 0) __hip_atomic_store(pc.pubp, SB6_FIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (w != 0) return;
-        if (tid == 0) {                                       // the first workgroup writes d, e once both are done
+        if (tid == 0) {                                       // member 0 writes d, e once every member is done
+            const int np_ = pc.stride / 2;
             int spin = 0;
-            for (; spin < 8000000; ++spin) {
-                if (__hip_atomic_load(pc.pollp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= SB6_FIN) break;
-                __builtin_amdgcn_s_sleep(8);
-            }
+            for (int q = 1; q < np_; ++q)
+                for (; spin < 8000000; ++spin) {
+                    if (__hip_atomic_load(&pc.C->prog[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= SB6_FIN) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
             if (spin >= 8000000) { atomicExch(&pc.C->err, 2); if (status) atomicExch(status, BSP_ERR_HIP); }
         }
         __syncthreads();
@@ -1558,7 +1578,10 @@ __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, int batc
     }
 }
 
-size_t sb2st_ctl_bytes(int batch) { return (size_t)batch * sizeof(Sb6Ctl); }
+size_t sb2st_ctl_bytes(int batch)
+{
+    return (size_t)batch * (sizeof(Sb8Ctl) > sizeof(Sb6Ctl) ? sizeof(Sb8Ctl) : sizeof(Sb6Ctl));
+}
 
 int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st, int *d_status,
                  void *ctl)
@@ -1613,22 +1636,30 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
         const bool chk = getenv("BSP_SB2ST_CHECK") != nullptr;
         if (chk && !d_chk) BSP_HIP(hipMalloc(reinterpret_cast<void **>(&d_chk), sizeof(int)));
         if (chk) BSP_HIP(hipMemsetAsync(d_chk, 0, sizeof(int), st));
-        static Sb6Ctl *s_ctl7 = nullptr;
-        static int cap7 = 0;
-        Sb6Ctl *d_ctl = nullptr;
+        static Sb8Ctl *s_ctl7 = nullptr;
+        static int cap7 = 0, ring_env = -1;
+        if (ring_env < 0) { const char *e = getenv("BSP_SB2ST_RING"); ring_env = e ? atoi(e) : 0; }
+        Sb8Ctl *d_ctl = nullptr;
+        // ring size: as many workgroups per channel as the chip has CUs for (each needs a whole CU), at most 8;
+        // 128 channels -> pairs, 32 channels -> rings of 8 (16 sweeps in flight per channel)
+        int P = 1;
         if (ver == 8) {
-            d_ctl = static_cast<Sb6Ctl *>(ctl);
+            P = ring_env > 0 ? ring_env : (batch > 64 ? 2 : (batch > 32 ? 4 : 8));
+            if (P > SB8_MAXP) P = SB8_MAXP;
+            while (P > 1 && n / SB < 9 * P) P /= 2;           // a sweep shorter than the ring's latency cannot fill it
+            if (P < 2) P = 2;
+            d_ctl = static_cast<Sb8Ctl *>(ctl);
             if (!d_ctl) {
                 if (cap7 < batch) {
                     if (s_ctl7) hipFree(s_ctl7);
-                    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&s_ctl7), (size_t)batch * sizeof(Sb6Ctl)));
+                    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&s_ctl7), (size_t)batch * sizeof(Sb8Ctl)));
                     cap7 = batch;
                 }
                 d_ctl = s_ctl7;
             }
-            BSP_HIP(hipMemsetAsync(d_ctl, 0, (size_t)batch * sizeof(Sb6Ctl), st));
+            BSP_HIP(hipMemsetAsync(d_ctl, 0, (size_t)batch * sizeof(Sb8Ctl), st));
         }
-        const int nblk = (ver == 8) ? ((batch + 7) / 8) * 16 : batch;
+        const int nblk = (ver == 8) ? ((batch + 7) / 8) * 8 * P : batch;
         const size_t lds = (sizeof(Sb7Shared) + 1023) / 1024 * 1024;
         static int diag7 = -1, margin = SB6_MARGIN, lead = 16, hyst = 2;   // measured: holds 13k -> 1.6k per channel with the lead   // measured: 243 ms (hyst 2) .. 258 ms (hyst 16)
         if (diag7 < 0) {
@@ -1641,7 +1672,7 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
             long long *dbuf = nullptr, h[96];
             BSP_HIP(hipMalloc(reinterpret_cast<void **>(&dbuf), sizeof(h)));
             hipLaunchKernelGGL(sb2st_kernel_v7<1>, dim3(nblk), dim3(512), lds, st, n, npad, batch, d_AB, d_d, d_e,
-                               chk ? d_chk : d_status, dbuf, d_ctl, margin, hyst, lead);
+                               chk ? d_chk : d_status, dbuf, d_ctl, P, margin, hyst, lead);
             BSP_HIP(hipStreamSynchronize(st));
             BSP_HIP(hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost));
             hipFree(dbuf);
@@ -1655,23 +1686,28 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
             }
         } else
         hipLaunchKernelGGL(sb2st_kernel_v7<0>, dim3(nblk), dim3(512), lds, st, n, npad, batch, d_AB, d_d, d_e,
-                           chk ? d_chk : d_status, (long long *)nullptr, d_ctl, margin, hyst, lead);
+                           chk ? d_chk : d_status, (long long *)nullptr, d_ctl, P, margin, hyst, lead);
         if (chk) {
             int hv = 0;
             BSP_HIP(hipStreamSynchronize(st));
             BSP_HIP(hipMemcpy(&hv, d_chk, sizeof(int), hipMemcpyDeviceToHost));
             if (hv) fprintf(stderr, "bspatom: sb2st v7 exchange-frame / pairing failure (status %d)\n", hv);
             if (d_ctl) {
-                std::vector<Sb6Ctl> hc(batch);
-                BSP_HIP(hipMemcpy(hc.data(), d_ctl, (size_t)batch * sizeof(Sb6Ctl), hipMemcpyDeviceToHost));
+                std::vector<Sb8Ctl> hc(batch);
+                BSP_HIP(hipMemcpy(hc.data(), d_ctl, (size_t)batch * sizeof(Sb8Ctl), hipMemcpyDeviceToHost));
                 int nerr = 0, nsolo = 0;
-                double nw = 0;
-                double nw1 = 0, nw2 = 0;
-                for (auto &c : hc) { nerr += c.err != 0; nsolo += (c.pair >> 31) || (((c.pair >> 8) ^ c.pair) & 0xf); nw += c.nwait[0]; nw1 += c.nwait[1]; nw2 += c.wcycles[0]; }
-                fprintf(stderr, "bspatom: sb2st v8: %d channels, %d alone, %d errors, %.1f holds per channel (%.1f in the first half of the sweeps, %.1f before item 0)\n", batch, nsolo, nerr,
-                        nw / batch, nw1 / batch, nw2 / batch);
+                double nw = 0, nw1 = 0, nw2 = 0;
+                for (auto &c : hc) {
+                    nerr += c.err != 0;
+                    bool same = !(c.hs & SB8_ABORT);
+                    for (int q = 1; q < P; ++q) same = same && (((c.hs >> (8 * q)) & 0xf) == (c.hs & 0xf));
+                    nsolo += !same;
+                    nw += c.nwait[0]; nw1 += c.nwait[1]; nw2 += c.wcycles[0];
+                }
+                fprintf(stderr, "bspatom: sb2st v8: %d channels, rings of %d, %d alone, %d errors, %.1f holds per channel (%.1f in the first half of the sweeps, %.1f before item 0)\n",
+                        batch, P, nsolo, nerr, nw / batch, nw1 / batch, nw2 / batch);
                 for (int c = 0, shown = 0; c < batch && shown < 8; ++c)
-                    if (hc[c].err) { fprintf(stderr, "  channel %d: err %d pair %08x prog %llx %llx\n", c, hc[c].err, hc[c].pair, hc[c].prog[0], hc[c].prog[1]); ++shown; }
+                    if (hc[c].err) { fprintf(stderr, "  channel %d: err %d handshake %016llx\n", c, hc[c].err, hc[c].hs); ++shown; }
                 if (nerr) return BSP_ERR_HIP;
             }
             if (hv) return BSP_ERR_HIP;

@@ -27,4 +27,6 @@ def main(reps=8, nl=128):
     return bad
 
 if __name__ == "__main__":
-    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 8) else 0)
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    nl = int(sys.argv[2]) if len(sys.argv) > 2 else 128        # 128: pairs; 64: rings of 4; 32: rings of 4 (n = 4096)
+    sys.exit(1 if main(reps, nl) else 0)
