@@ -1646,7 +1646,9 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
         if (ver == 8) {
             P = ring_env > 0 ? ring_env : (batch > 64 ? 2 : (batch > 32 ? 4 : 8));
             if (P > SB8_MAXP) P = SB8_MAXP;
-            while (P > 1 && n / SB < 9 * P) P /= 2;           // a sweep shorter than the ring's latency cannot fill it
+            if (ring_env <= 0)
+                while (P > 2 && n / SB < 3 * P) P /= 2;       // measured: rings beyond a sweep's length (n/64 items) still
+                                                              // help down to about a third of it (n = 2048: 57 -> 46 ms)
             if (P < 2) P = 2;
             d_ctl = static_cast<Sb8Ctl *>(ctl);
             if (!d_ctl) {
