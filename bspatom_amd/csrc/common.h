@@ -52,6 +52,9 @@ int gemm_f64(const GemmDesc &g, hipStream_t st);
 // with a small C and a long K: one tile per channel cannot fill the chip); `part` holds splits * batch * M * N
 // doubles; the slices are summed in a fixed order (deterministic).
 int gemm_splitk_f64(const GemmDesc &g, int splits, double *part, hipStream_t st);
+// C[b] (m x 64) = alpha * A[b] (m x 64) * B[b] (64 x 64, ld 64) + beta * C[b], column-major (gemm_f64.hip)
+int tsmm64_f64(int m, int batch, const double *A, long lda, long bsA, const double *B, long bsB, double *C, long ldc, long bsC,
+               double alpha, double beta, hipStream_t st);
 // pipelined, symmetry-aware products of sy2sb (see gemm_f64.hip)
 // part: 0 = all tiles, 1 = only column block 0 (look-ahead part), 2 = column blocks >= 1
 int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const double *buf, long ldb, long bsBuf,

@@ -188,6 +188,79 @@ int gemm_f64(const GemmDesc &gin, hipStream_t st)
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Tall-skinny times small square: C[b] (m x 64) = alpha * A[b] (m x 64) * B[b] (64 x 64) + beta * C[b], all
+// column-major (W = V T and Z = Y - 1/2 V K of sy2sb: twice per panel, on the stage's critical chain, and
+// memory-bound: 16 flop/B).  The general kernel stages A through LDS k-step by k-step with two barriers each;
+// here B (32 KB) is the only thing in LDS and every wave reads its 32 x 64 slab of A straight into MFMA operand
+// registers -- lane l holds A(row l & 15, column l >> 4), i.e. one instruction fetches four 128-byte column
+// segments -- with all 32 loads in flight before the first MFMA.  One workgroup = 128 rows.
+__global__ __launch_bounds__(256) void tsmm64_kernel(int m, const double *__restrict__ Aall, long lda, long bsA,
+                                                    const double *__restrict__ Ball, long bsB, double *Call, long ldc,
+                                                    long bsC, double alpha, double beta)
+{
+    __shared__ double Bs[64][64 + 2];                                  // Bs[k][n]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double *A = Aall + (long)blockIdx.y * bsA;
+    const double *B = Ball + (long)blockIdx.y * bsB;
+    double *C = Call + (long)blockIdx.y * bsC;
+    const int r0 = blockIdx.x * 128 + wave * 32;                       // this wave's 32 rows
+    for (int idx = tid; idx < 64 * 64; idx += 256) { const int kk = idx & 63, nn = idx >> 6; Bs[kk][nn] = B[kk + 64 * nn]; }
+    // A fragments: a[i][q] = A(r0 + 16 i + (lane & 15), 4 q + (lane >> 4)); rows beyond m read row 0 (masked at the store)
+    double a[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = r0 + 16 * i + (lane & 15);
+        const double *ap = A + (row < m ? row : 0) + (long)(lane >> 4) * lda;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[i][q] = ap[(long)(4 * q) * lda];
+    }
+    double4_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        double b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = Bs[4 * q + (lane >> 4)][16 * j + (lane & 15)];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j], a[i][q], acc[i][j], 0, 0, 0);
+    }
+    // The product is formed TRANSPOSED (C^T = B^T A^T: the B fragment as the MFMA's first operand, the A fragment as its
+    // second; the two register layouts are each other's transposes), so that acc[i][j][r] = C(r0 + 16 i + (lane & 15),
+    // 16 j + (lane >> 4) + 4 r): the 16 lanes of a DPP row store 16 consecutive rows of one column of the
+    // column-major C -- whole 128-byte lines
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + 16 * i + (lane & 15), col = 16 * j + (lane >> 4) + 4 * r;
+                if (row < m) {
+                    double *p = C + row + (long)col * ldc;
+                    double v = alpha * acc[i][j][r];
+                    if (beta != 0.0) v += beta * (*p);
+                    *p = v;
+                }
+            }
+}
+
+int tsmm64_f64(int m, int batch, const double *A, long lda, long bsA, const double *B, long bsB, double *C, long ldc, long bsC,
+               double alpha, double beta, hipStream_t st)
+{
+    if (m <= 0 || batch <= 0) return BSP_OK;
+    hipLaunchKernelGGL(tsmm64_kernel, dim3((m + 127) / 128, batch), dim3(256), 0, st, m, A, lda, bsA, B, bsB, C, ldc, bsC, alpha,
+                       beta);
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
+
 // sum of the split-K slices in slice order: C(i,j) = sum_s part[s][b][i*N + j] (+ beta * C)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const double *__restrict__ part, int splits, int batch, int M, int N,
                                                            double *Call, long sCm, long sCn, long bC, double beta)

@@ -619,12 +619,8 @@ static int panel_and_W(int npad, int c0, int batch, double *d_A, double *buf, do
     if ((rc = gemm_splitk_f64(g, SY2SB_SPLITK, w.part, s))) return rc;   // 64 x 64 x m: one tile per channel
     hipLaunchKernelGGL(form_T_kernel, dim3(batch), dim3(64), 0, s, w.G, tau, w.T);
     BSP_HIP(hipGetLastError());
-    // W = V T
-    g.M = m; g.N = NB; g.K = NB;
-    g.A = buf; g.sAm = 1; g.sAk = npad; g.bA = bsBuf;
-    g.B = w.T; g.sBk = 1; g.sBn = NB; g.bB = bsS;
-    g.C = w.W; g.sCm = 1; g.sCn = npad; g.bC = bsW; g.alpha = 1.0; g.beta = 0.0;
-    return gemm_f64(g, s);
+    // W = V T   (m x 64 times 64 x 64)
+    return tsmm64_f64(m, batch, buf, npad, bsBuf, w.T, bsS, w.W, npad, bsW, 1.0, 0.0, s);
 }
 
 // Look-ahead schedule: after the block column that holds the next panel has been updated (syr2k
@@ -663,12 +659,8 @@ static int sy2sb_panel(int npad, int batch, double *d_A, const Sy2sbWork &w, hip
         g.B = buf + (size_t)NB * npad; g.sBk = 1; g.sBn = npad; g.bB = bsBuf;
         g.C = w.Kmat; g.sCm = 1; g.sCn = NB; g.bC = bsS; g.alpha = 1.0; g.beta = 0.0;
         if ((rc = gemm_splitk_f64(g, SY2SB_SPLITK, w.part, st))) return rc;
-        // Z = Y - 1/2 V K  (in place)
-        g.M = m; g.N = NB; g.K = NB;
-        g.A = buf; g.sAm = 1; g.sAk = npad; g.bA = bsBuf;
-        g.B = w.Kmat; g.sBk = 1; g.sBn = NB; g.bB = bsS;
-        g.C = buf + (size_t)NB * npad; g.sCm = 1; g.sCn = npad; g.bC = bsBuf; g.alpha = -0.5; g.beta = 1.0;
-        if ((rc = gemm_f64(g, st))) return rc;
+        // Z = Y - 1/2 V K  (in place; m x 64 times 64 x 64)
+        if ((rc = tsmm64_f64(m, batch, buf, npad, bsBuf, w.Kmat, bsS, buf + (size_t)NB * npad, npad, bsBuf, -0.5, 1.0, st))) return rc;
         // A22 -= [V Z] [Z V]^T
         const bool more = (p + 1 < P);
         if (lookahead && more) {
