@@ -1,9 +1,11 @@
 !  bsp_atom_host.f90 -- Fortran host of libbspatom (ISO_C_BINDING over the C ABI in
-!  include/bspatom.h).  Drop-in for `Bsp_Atom_omp.x < bsp_0.inp` in KIND_PI = 0 mode:
+!  include/bspatom.h).  Drop-in for `Bsp_Atom_omp.x < bsp_0.inp` up to the end of SOLVE_SYSTEM:
 !  reads the three NAMELIST groups from stdin exactly as READ_INPUTS does (reference
 !  src/ReadInputs.f90:15-21,27-37,75-85,155-184), solves all l-channels on the MI355X, and
 !  writes stdout, Enl.dat and wf_n0.dat in the reference's formats
-!  (src/matrices.f90:239-240,256-265,388-391; src/Bsp_Atom.f90:118-146).
+!  (src/matrices.f90:239-240,256-265,388-391; src/Bsp_Atom.f90:118-146).  KIND_PI = 0 ends there;
+!  KIND_PI >= 3 also reproduces the state limits and Eigenvec_All.dat (src/matrices.f90:290-378);
+!  the photo-ionisation branches that follow SOLVE_SYSTEM in the reference are not part of this host.
       MODULE BSPATOM_C
       USE ISO_C_BINDING
       IMPLICIT NONE
@@ -49,6 +51,12 @@
           INTEGER(C_INT), VALUE :: l, n0
           REAL(C_DOUBLE), INTENT(OUT) :: c(*)
         END FUNCTION
+        INTEGER(C_INT) FUNCTION bspatom_eigvecs(prob, l, n0, cnt, Z) BIND(C, NAME='bspatom_eigvecs')
+          IMPORT :: C_INT, C_PTR, C_DOUBLE
+          TYPE(C_PTR), VALUE :: prob
+          INTEGER(C_INT), VALUE :: l, n0, cnt
+          REAL(C_DOUBLE), INTENT(OUT) :: Z(*)
+        END FUNCTION
         INTEGER(C_INT) FUNCTION bspatom_write_wf(prob, c, npts, r, u) BIND(C, NAME='bspatom_write_wf')
           IMPORT :: C_INT, C_PTR, C_DOUBLE
           TYPE(C_PTR), VALUE :: prob
@@ -84,6 +92,11 @@
       TYPE(C_PTR) :: prob
       INTEGER(C_INT) :: rc
       INTEGER :: l, i, npts
+!     KIND_PI >= 3 bookkeeping (names as in SOLVE_SYSTEM)
+      INTEGER :: n0_fin, n1_fin, nlim, nbds, nbold, ntemp, nE0, n1_max, ni, ntemp0
+      INTEGER, ALLOCATABLE :: n01(:,:)
+      REAL(DP) :: Elim, Ei
+      REAL(DP), ALLOCATABLE :: Zl(:,:)
       REAL(DP), ALLOCATABLE :: En(:), ci(:), r(:), u(:)
       INTEGER(C_INT32_T), ALLOCATABLE :: info(:)
 
@@ -101,8 +114,8 @@
       b0 = 0.D0; afocus = 0.D0; nEpts = 10; Eref = 0.D0; nthpts = 1; nphpts = 1; ncyc = 0
       bx = 0.D0; B0z = 0.D0; t_delay = 0.D0; ncyc2 = 0; Eph2 = 0.D0; A0x = 0.D0; A0y = 0.D0; A0z = 1.D0
       READ(5,VARS_FIELD)
-      IF( KIND_PI /= 0 ) THEN
-        WRITE(6,*) 'bsp_atom_host: only KIND_PI = 0 (electronic structure) is on the MI355X hot path'
+      IF( KIND_PI == 1 .OR. KIND_PI == 2 ) THEN
+        WRITE(6,*) 'bsp_atom_host: KIND_PI = 1, 2 continue into TRANS_AMP, which is not on the MI355X hot path'
         STOP 2
       END IF
 
@@ -139,6 +152,8 @@
       END IF
       WRITE(6,'(A19,/)') 'Matrices Calculated'
 
+      n0_fin = -1; n1_fin = -1; nlim = 0; nbds = 0; ntemp = 0; ntemp0 = 0
+      IF( KIND_PI >= 3 ) ALLOCATE( n01(0:lmax,3) )
       OPEN( UNIT=75, FILE='Enl.dat', ACTION='WRITE' )
       WRITE(75,*) nfun
       DO l = 0, lmax
@@ -175,13 +190,73 @@
           CLOSE(30)
           DEALLOCATE( r, u )
         END IF
+        IF( KIND_PI >= 3 ) THEN
+!         state limits of this channel (matrices.f90:290-328); n0_fin, n1_fin, ntemp, Emax_fin deliberately
+!         persist from channel to channel, as they do in the reference
+          IF( Emax_fin == -1.0D0 ) THEN
+            Emax_fin = En(l*nfun+nfun)
+            Elim = Emax_fin
+          ELSE IF( KIND_PI >= 8 ) THEN
+            Elim = Emax_fin
+          ELSE
+            Elim = Emax_fin + 0.25D0
+          END IF
+          nbold = 0
+          DO i = 1, nfun
+            Ei = En(l*nfun+i)
+            IF( Ei < 0.D0 ) THEN
+              n0_fin = i
+              nbold = nbold + 1
+            END IF
+            IF( Ei <= Emax_fin ) n1_fin = i
+            IF( Ei <= Elim ) ntemp = i
+            IF( Ei > Emax_fin .AND. Ei > Elim ) EXIT
+          END DO
+          nbds = MAX(nbds,nbold)
+          nE0 = n0_fin + 1
+          n0_fin = nE0
+          n1_fin = n1_fin + 1
+          IF( KIND_PI >= 5 ) n0_fin = 1
+          nlim = MAX(nlim,ntemp)
+          n01(l,1) = n0_fin; n01(l,2) = n1_fin; n01(l,3) = nE0 - 1
+          WRITE(6,'(/,A23,I3)') 'NUMBER OF BOUND STATES:', nbold
+          WRITE(6,'(A14,I3,A6,2I5)') 'LIMITS FOR l =', l, ' STATE:', n0_fin+l, n1_fin+l
+          ntemp = MIN(MAX(n1_fin+40,nlim),nfun)
+          IF( l == 0 ) ntemp0 = ntemp
+        END IF
       END DO
       CLOSE(75)
+
+      IF( KIND_PI >= 3 ) THEN
+!       Eigenvec_All.dat (matrices.f90:355-378): the first n1_max eigenvectors of every channel
+        n1_max = MIN(MAX(MAXVAL(n01(:,2))+20,nlim),nfun)
+        WRITE(6,'(A8,I5)') 'n1_max =', n1_max
+        IF( n1_max > ntemp0 ) THEN
+          WRITE(6,*) 'bsp_atom_host: n1_max exceeds the vectors the reference keeps (ctemp)'
+          STOP 1
+        END IF
+        ALLOCATE( Zl(nfun,n1_max) )
+        OPEN( UNIT=80, FILE='Eigenvec_All.dat', ACTION='WRITE' )
+        WRITE(80,*) nfun, n1_max, lmax
+        DO l = 0, lmax
+          rc = bspatom_eigvecs(prob, INT(l,C_INT), 1_C_INT, INT(n1_max,C_INT), Zl)
+          IF( rc /= 0 ) THEN
+            WRITE(6,*) 'bsp_atom_host: bspatom_eigvecs failed, code ', rc
+            STOP 1
+          END IF
+          WRITE(80,*) l
+          DO ni = 1, n1_max
+            WRITE(80,300) ni, (Zl(i,ni), i=1,nfun)
+          END DO
+        END DO
+        CLOSE(80)
+      END IF
       CALL bspatom_problem_destroy(prob)
-      WRITE(6,'(/,A17)') 'Program Finished!'
+      IF( KIND_PI == 0 ) WRITE(6,'(/,A17)') 'Program Finished!'
 
 100   FORMAT(/,T2,A5,I2)
 110   FORMAT(T2,A26,/)
 120   FORMAT(T5,A1,T9,A11)
 200   FORMAT(T2,I4,T8,G22.15)
+300   FORMAT(I5,5000G20.10)
       END PROGRAM BSP_ATOM_MI355X

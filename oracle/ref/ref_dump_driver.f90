@@ -37,6 +37,18 @@
 !     (Continuing into TRANS_AMP / CROSS_SECTIONS for KIND_PI = 1, 2, as PROGRAM BSP_ATOM_PI does, is not
 !     possible with this build: TRANS_AMP prints Enl(1,lf), PhotoIon.f90:45, which SOLVE_SYSTEM allocates for
 !     KIND_PI >= 3 only -- the compiled reference segfaults there, so no amplitude fixtures exist.)
+!     KIND_PI >= 3: the state-selection bookkeeping SOLVE_SYSTEM leaves in the module (matrices.f90:290-358):
+!     n01(l,1:3), n1_max, Emax_fin as modified, the spectra Enl and the density-of-states factors rEki, for
+!     SURVEY 8(f).1 (the eigenvectors themselves are read from the Eigenvec_All.dat the same run wrote)
+      IF( KIND_PI >= 3 .AND. ALLOCATED(n01) ) THEN
+        OPEN(UNIT=93, FILE='ref_pi3.bin', ACCESS='STREAM', FORM='UNFORMATTED', ACTION='WRITE')
+        WRITE(93) nfun, lmax, n1_max, KIND_PI
+        WRITE(93) n01(0:lmax,1:3)
+        WRITE(93) Emax_fin
+        WRITE(93) Enl(1:nfun,0:lmax)
+        WRITE(93) rEki(1:nfun,0:lmax)
+        CLOSE(93)
+      END IF
       WRITE(6,'(A,F12.4)') 'REF_TIME_MATRIX_SVT_S ', DBLE(c1-c0)/DBLE(crate)
       WRITE(6,'(A,F12.4)') 'REF_TIME_SOLVE_SYSTEM_S ', DBLE(c2-c1)/DBLE(crate)
       END PROGRAM REF_DUMP

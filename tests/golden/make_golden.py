@@ -15,6 +15,8 @@ Manifest (compiler, LAPACK) is written to tests/golden/MANIFEST.json.
 
 usage: python tests/golden/make_golden.py [case ...]      (default: all small cases)
        python tests/golden/make_golden.py --big            (adds the n=2048/4096 spectra)
+       python tests/golden/make_golden.py --dipole         (KIND_PI = 1, 2 dipole matrices rij)
+       python tests/golden/make_golden.py --pi3            (KIND_PI >= 3: state limits, rEki, Eigenvec_All.dat)
 """
 import json, os, subprocess, sys, tempfile, time
 import numpy as np
@@ -109,6 +111,58 @@ def run_dipole(name, text, kind_pi):
     print("%-12s nfun=%4d k=%2d KIND_PI=%d  |r1|max %.6g |r2|max %.6g outside band %.1e" % (
         name, nfun, k, kind_pi, np.max(np.abs(out["r1f"])), np.max(np.abs(out["r2f"])), out["outside_band_max"][0]), flush=True)
 
+# KIND_PI >= 3 branch of SOLVE_SYSTEM (matrices.f90:290-378): state limits n01, n1_max, density-of-states
+# factors rEki and the Eigenvec_All.dat file.  name -> namelist
+def nml_pi3(bsp, tise, kind_pi):
+    return "&VARS_BSP %s &end\n&VARS_TISE %s &end\n&VARS_FIELD KIND_PI=%d Eph=0.5D0 I0=1.0D14 &end\n" % (bsp, tise, kind_pi)
+
+_B64 = "KIND_GRID=0 ra=0.0D0 rb=50.0D0 k=7 nfun=64"
+PI3 = {
+    "pi3_emax1": nml_pi3(_B64, "n0_ini=1 l_ini=0 l_fin=2 Emax_fin=1.0D0 Zatom=1.0D0", 3),
+    "pi3_default": nml_pi3(_B64, "n0_ini=1 l_ini=0 l_fin=2 Zatom=1.0D0", 3),           # Emax_fin = -1 -> En(nfun) of l = 0
+    "pi5_emax05": nml_pi3(_B64, "n0_ini=2 l_ini=1 l_fin=2 Emax_fin=0.5D0 Zatom=1.0D0", 5),   # KIND_PI >= 5: n0_fin = 1
+    "pi8_emax1": nml_pi3(_B64, "n0_ini=1 l_ini=0 l_fin=2 Emax_fin=1.0D0 Zatom=1.0D0", 8),     # KIND_PI >= 8: Elim = Emax_fin
+    # small box: no bound state for l >= 2, the limits carry over from the previous channel (matrices.f90:305-316)
+    "pi3_nobound": nml_pi3("KIND_GRID=0 ra=0.0D0 rb=6.0D0 k=5 nfun=40", "n0_ini=1 l_ini=0 l_fin=3 Emax_fin=4.0D0 Zatom=1.0D0", 3),
+}
+
+def run_pi3(name, text):
+    inp = os.path.join(HERE, "inputs", name + ".inp")
+    with open(inp, "w") as f:
+        f.write("! golden-fixture input '%s' (generated by make_golden.py)\n" % name)
+        f.write(text)
+    with tempfile.TemporaryDirectory(prefix="bspgold.") as tmp:
+        with open(inp) as fin:
+            p = subprocess.run([REFX], stdin=fin, cwd=tmp, capture_output=True, text=True)
+        if p.returncode != 0:
+            raise RuntimeError("reference failed on %s:\n%s\n%s" % (name, p.stdout[-2000:], p.stderr[-2000:]))
+        raw = open(os.path.join(tmp, "ref_pi3.bin"), "rb").read()
+        nfun, lmax, n1_max, kind_pi = [int(v) for v in np.frombuffer(raw[:16], dtype=np.int32)]
+        off = 16
+        n01 = np.frombuffer(raw[off: off + 4 * 3 * (lmax + 1)], dtype=np.int32).reshape(3, lmax + 1).T.copy(); off += 4 * 3 * (lmax + 1)
+        emax = np.frombuffer(raw[off: off + 8], dtype=np.float64).copy(); off += 8
+        nn = nfun * (lmax + 1)
+        E = np.frombuffer(raw[off: off + 8 * nn], dtype=np.float64).reshape(lmax + 1, nfun).copy(); off += 8 * nn
+        reki = np.frombuffer(raw[off: off + 8 * nn], dtype=np.float64).reshape(lmax + 1, nfun).copy(); off += 8 * nn
+        assert off == len(raw)
+        lines = open(os.path.join(tmp, "Eigenvec_All.dat")).read().split("\n")
+        hdr = [int(t) for t in lines[0].split()]
+        assert hdr == [nfun, n1_max, lmax]
+        C = np.zeros((lmax + 1, n1_max, nfun))
+        pos = 1
+        for l in range(lmax + 1):
+            assert int(lines[pos].split()[0]) == l; pos += 1
+            for ni in range(n1_max):
+                ln = lines[pos]; pos += 1
+                assert int(ln[:5]) == ni + 1
+                C[l, ni] = [float(ln[5 + 20 * i: 25 + 20 * i]) for i in range(nfun)]
+        sel = [l for l in p.stdout.split("\n") if ("BOUND STATES" in l or "LIMITS FOR" in l or "n1_max" in l)]
+        out = dict(sizes=np.array([nfun, lmax, n1_max, kind_pi]), n01=n01, emax_fin_out=emax, E=E, reki=reki, C=C,
+                   eva_head=np.array("\n".join(lines[:2])), eva_row=np.array(lines[2]), limits=np.array("\n".join(sel)),
+                   stdout=np.array(p.stdout), namelist=np.array(open(inp).read()))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("%-12s nfun=%3d lmax=%d KIND_PI=%d n1_max=%d n01=%s" % (name, nfun, lmax, kind_pi, n1_max, n01.tolist()), flush=True)
+
 def upper_band(M, k):
     n = M.shape[0]
     B = np.zeros((k, n))
@@ -191,8 +245,16 @@ def main():
         for name in (args or list(DIPOLE)):
             run_dipole(name, *DIPOLE[name])
         return
+    if "--pi3" in args:
+        args.remove("--pi3")
+        for name in (args or list(PI3)):
+            run_pi3(name, PI3[name])
+        return
     sel = args or list(cases)
     for name in sel:
+        if name in PI3:
+            run_pi3(name, PI3[name])
+            continue
         if name in DIPOLE:
             run_dipole(name, *DIPOLE[name])
             continue

@@ -175,3 +175,53 @@ def test_eigenvec_all_format_cpu(tmp_path):
     for l in range(3):
         Z = FakeProblem().eigvecs(l, 1, 5)
         assert np.max(np.abs(c[l] - Z) / np.abs(Z)) < 1e-9
+
+
+PI3_CASES = ["pi3_emax1", "pi3_default", "pi5_emax05", "pi8_emax1", "pi3_nobound"]
+
+
+@pytest.mark.parametrize("name", PI3_CASES)
+def test_select_states_vs_reference(name):
+    """State limits of SOLVE_SYSTEM's KIND_PI >= 3 branch (matrices.f90:290-341, :355-358) on the reference's own
+    spectra (binary dump of Enl): n01, n1_max, the modified Emax_fin and the density-of-states factors rEki must be
+    IDENTICAL to what the compiled reference left in its module (integers equal, doubles bit-equal); the stdout
+    lines it printed must be reproduced character by character.  pi3_nobound has channels without bound states,
+    where the reference carries n0_fin over from the previous channel."""
+    from bspatom_amd import host
+    g = load_golden(name)
+    nfun, lmax, n1_max, kind_pi = (int(v) for v in g["sizes"])
+    em = read_namelists(str(g["namelist"]))["vars_tise"].get("emax_fin", -1.0)
+    lim = host.select_states(g["E"], em, kind_pi)
+    assert np.array_equal(lim.n01, g["n01"])
+    assert lim.n1_max == n1_max
+    assert lim.emax_fin == g["emax_fin_out"][0]
+    assert np.array_equal(lim.reki, g["reki"])
+    mine = []
+    for l in range(lmax + 1):
+        mine.append("NUMBER OF BOUND STATES:%3d" % lim.nbold[l])
+        mine.append("LIMITS FOR l =%3d STATE%5d%5d" % (l, lim.n01[l, 0] + l, lim.n01[l, 1] + l))
+    mine.append("n1_max =%5d" % lim.n1_max)
+    assert mine == [x.rstrip() for x in str(g["limits"]).split("\n")]
+
+
+@pytest.mark.parametrize("name", PI3_CASES)
+def test_eigenvec_all_text_matches_reference_file(tmp_path, name):
+    """The writer on the reference's own eigenvector values must reproduce the reference's Eigenvec_All.dat text:
+    header and channel lines (list-directed, flang spelling) and the first record (I5 + nfun G20.10 fields)."""
+    from bspatom_amd import host
+    g = load_golden(name)
+    nfun, lmax, n1_max, _ = (int(v) for v in g["sizes"])
+    C = g["C"]
+
+    class RefVectors:
+        pass
+    rv = RefVectors(); rv.nfun = nfun
+    rv.eigvecs = lambda l, n0, count: C[l, n0 - 1: n0 - 1 + count]
+    p = tmp_path / "Eigenvec_All.dat"
+    host.write_eigenvec_all(str(p), rv, lmax, n1_max)
+    lines = open(p).read().split("\n")
+    assert "\n".join(lines[:2]) == str(g["eva_head"])
+    assert lines[2] == str(g["eva_row"])
+    assert len(lines) == 1 + (lmax + 1) * (1 + n1_max) + 1
+    _, _, _, c = host.read_eigenvec_all(str(p))
+    assert np.array_equal(c, C)                      # 10-digit text -> the same doubles the fixture parsed
