@@ -192,3 +192,28 @@ def read_eigenvec_all(path):
                 c[l, ni] = [float(line[5 + 20 * i: 25 + 20 * i]) for i in range(nfun)]
     return nfun, n1, lmax, c
 
+
+
+def read_enl(path, lmax, emax_fin=-1.0):
+    """Reads `Enl.dat` back the way the reference's consumers do (READ_FR, ReadInputs.f90:292-316): list-directed
+    `nfun`, then (lmax+1)*nfun records `i, En`; returns (nfun, Enl[l][i], n01[l]) with n01 = (1, n1_fin, n0_fin) as
+    that reader rebuilds it (last index with En <= Emax_fin, last index with En < 0, both carried over between
+    channels and starting undefined in the reference: 0 here)."""
+    import numpy as np
+    with open(path) as f:
+        nfun = int(f.readline().split()[0])
+        E = np.zeros((lmax + 1, nfun)); n01 = np.zeros((lmax + 1, 3), dtype=np.int64)
+        n0_fin = 0; n1_fin = 0
+        for l in range(lmax + 1):
+            for ni in range(1, nfun + 1):
+                t = f.readline().replace(",", " ").split()
+                if len(t) < 2:
+                    raise ValueError("Error Reading Energies")
+                e = float(t[1].replace("D", "E").replace("d", "e"))
+                E[l, ni - 1] = e
+                if e < 0.0:
+                    n0_fin = ni
+                if e <= emax_fin:
+                    n1_fin = ni
+            n01[l] = (1, n1_fin, n0_fin)
+    return nfun, E, n01

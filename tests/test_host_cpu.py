@@ -225,3 +225,23 @@ def test_eigenvec_all_text_matches_reference_file(tmp_path, name):
     assert len(lines) == 1 + (lmax + 1) * (1 + n1_max) + 1
     _, _, _, c = host.read_eigenvec_all(str(p))
     assert np.array_equal(c, C)                      # 10-digit text -> the same doubles the fixture parsed
+
+
+def test_enl_reader_on_reference_text(tmp_path):
+    """Enl.dat as the reference wrote it (rebuilt from the golden stdout/E values in its FORMAT(T2,I4,T8,G22.15))
+    through the READ_FR-style reader: 15 significant digits come back, limits follow ReadInputs.f90:305-312."""
+    from bspatom_amd import host
+    g = load_golden("pi3_emax1")
+    E = g["E"]; nl, nfun = E.shape
+    p = tmp_path / "Enl.dat"
+    with open(p, "w") as f:
+        f.write(" %d\n" % nfun)
+        for l in range(nl):
+            for i in range(nfun):
+                f.write(" %4d  %s\n" % (i + 1, fortran_g(E[l, i], 22, 15)))
+    nf, Er, n01 = host.read_enl(str(p), nl - 1, emax_fin=1.0)
+    assert nf == nfun
+    assert np.max(np.abs(Er - E) / np.abs(E)) < 1e-14
+    # the reader's limits differ from SOLVE_SYSTEM's by the +1 the latter adds (matrices.f90:315-316)
+    assert np.array_equal(n01[:, 1], g["n01"][:, 1] - 1)
+    assert np.array_equal(n01[:, 2], g["n01"][:, 2])
