@@ -239,6 +239,160 @@ __global__ __launch_bounds__(256) void bisect2_kernel(int n, int ldn, const doub
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Third form: the same recurrence with less bookkeeping per row, and a shared first level.
+//   * (d_i, e_{i-1}^2) are interleaved: one 16-byte LDS broadcast per row;
+//   * the sign bit of every p_i is shifted into a 32-bit history word (one v_alignbit per row); the sign changes of
+//     32 rows are counted at once, popcount(h ^ (h >> 1 | previous word's last bit << 31)): three instructions per
+//     32 rows instead of three per row;
+//   * renormalisation by max(exponent) without the zero special cases: v_frexp_exp of 0 is 0, which at worst skips
+//     one renormalisation (the block after an exact zero has none), far from the range limits (see RS above);
+//   * first level: the workgroup counts at 256*EPT uniformly spaced points of the Gershgorin interval in ONE
+//     evaluation round and every eigenvalue starts from the grid cell that brackets it -- ten bisection levels for
+//     the price of one; the search keeps the invariant count(lo) <= m < count(hi) and therefore needs no
+//     monotonicity of the computed counts.
+constexpr int HW = 32;     // rows per sign-history word (np is padded to a multiple of it)
+
+__device__ __forceinline__ void sturm_counts3(const double2 *__restrict__ de, int np, const double (&x)[EPT], int (&cnt)[EPT])
+{
+    double p0[EPT], p1[EPT];
+    unsigned h[EPT], hp[EPT];
+    const double d0 = de[0].x;
+#pragma unroll
+    for (int c = 0; c < EPT; ++c) {
+        p0[c] = 1.0; p1[c] = d0 - x[c];
+        hp[c] = (unsigned)__double2hiint(p1[c]) >> 31;      // p_0 = 1 > 0: a negative p_1 is the first sign change
+        cnt[c] = (int)hp[c]; h[c] = 0u;
+    }
+    for (int ib = 0; ib < np; ib += HW) {
+#pragma unroll
+        for (int sb = 0; sb < HW / RS; ++sb) {
+#pragma unroll
+            for (int r = 0; r < RS; ++r) {
+                const double2 v = de[ib + sb * RS + r + 1];  // rows 1 .. np
+#pragma unroll
+                for (int c = 0; c < EPT; ++c) {
+                    const double pn = __builtin_fma(v.x - x[c], p1[c], -(v.y * p0[c]));
+                    h[c] = __builtin_amdgcn_alignbit(h[c], (unsigned)__double2hiint(pn), 31);
+                    p0[c] = p1[c];
+                    p1[c] = pn;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < EPT; ++c) {
+                const int ea = __builtin_amdgcn_frexp_exp(p1[c]), eb = __builtin_amdgcn_frexp_exp(p0[c]);
+                const int ex = -max(ea, eb);
+                p1[c] = __builtin_amdgcn_ldexp(p1[c], ex);
+                p0[c] = __builtin_amdgcn_ldexp(p0[c], ex);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < EPT; ++c) {
+            const unsigned t = __builtin_amdgcn_alignbit(hp[c], h[c], 1);
+            cnt[c] += __builtin_popcount(h[c] ^ t);
+            hp[c] = h[c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bisect3_kernel(int n, int ldn, const double *__restrict__ dall,
+                                                     const double *__restrict__ eall, double *wall, long ldw)
+{
+    extern __shared__ double2 sde[];
+    constexpr int NG = 256 * EPT;
+    const int np = (n + HW - 1) / HW * HW;
+    double2 *de = sde;                                 // de[i] = (d_i, e_{i-1}^2), i = 0 .. np
+    int *cg = (int *)(sde + np + 1);                   // counts at the NG first-level points
+    __shared__ double red[8];
+    const int tid = threadIdx.x;
+    const size_t ch = blockIdx.y;
+    const double *dg = dall + ch * (size_t)ldn, *eg = eall + ch * (size_t)ldn;
+    double gl = 1e300, gu = -1e300;
+    for (int i = tid; i < n; i += 256) {
+        const double di = dg[i];
+        const double el = (i > 0) ? fabs(eg[i - 1]) : 0.0;
+        const double er = (i < n - 1) ? fabs(eg[i]) : 0.0;
+        gl = fmin(gl, di - el - er);
+        gu = fmax(gu, di + el + er);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        gl = fmin(gl, __shfl_xor(gl, off));
+        gu = fmax(gu, __shfl_xor(gu, off));
+    }
+    if ((tid & 63) == 0) { red[tid >> 6] = gl; red[4 + (tid >> 6)] = gu; }
+    __syncthreads();
+    gl = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+    gu = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+    const double eps = 2.220446049250313e-16;
+    double tnorm = fmax(fabs(gl), fabs(gu));
+    if (!(tnorm > 0.0)) tnorm = 1.0;                   // the zero matrix
+    int kexp;
+    (void)frexp(tnorm, &kexp);                         // tnorm = f 2^kexp, f in [0.5, 1)
+    const double sc = ldexp(1.0, -kexp), isc = ldexp(1.0, kexp);
+    for (int i = tid; i <= np; i += 256) {
+        // row i of the scaled matrix with its coupling to row i-1.  Padding rows: d = 2, coupling at the floor.
+        const double di = (i < n) ? dg[i] * sc : 2.0;
+        const double ev = (i >= 1 && i < n) ? (eg[i - 1] * sc) : 0.0;
+        de[i] = make_double2(di, fmax(ev * ev, 1e-60));
+    }
+    __syncthreads();
+    gl = gl * sc - 2.1 * eps * n - 1e-300;             // scaled Gershgorin interval, widened as dstebz does
+    gu = gu * sc + 2.1 * eps * n + 1e-300;
+
+    const int mbase = blockIdx.x * NG + tid;           // eigenvalue indices mbase + 256 c
+    double lo[EPT], hi[EPT];
+    {
+        // first level: NG interior points x_j = gl + (gu - gl) (j+1)/(NG+1), j = tid + 256 c
+        const double w = gu - gl;
+        double xg[EPT];
+        int cc[EPT];
+#pragma unroll
+        for (int c = 0; c < EPT; ++c) xg[c] = gl + w * ((double)(tid + 256 * c + 1) * (1.0 / (NG + 1)));
+        sturm_counts3(de, np, xg, cc);
+#pragma unroll
+        for (int c = 0; c < EPT; ++c) cg[tid + 256 * c] = cc[c];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < EPT; ++c) {
+            const int m = mbase + 256 * c;
+            int L = -1, R = NG;                        // count(x_L) <= m < count(x_R), with x_{-1} = gl, x_NG = gu
+            while (R - L > 1) {
+                const int mid = (L + R) >> 1;
+                if (cg[mid] > m) R = mid; else L = mid;
+            }
+            lo[c] = (L < 0) ? gl : gl + w * ((double)(L + 1) * (1.0 / (NG + 1)));
+            hi[c] = (R >= NG) ? gu : gl + w * ((double)(R + 1) * (1.0 / (NG + 1)));
+        }
+    }
+    for (int it = 0; it < 128; ++it) {
+        double mid[EPT];
+        bool done[EPT];
+        bool alld = true;
+#pragma unroll
+        for (int c = 0; c < EPT; ++c) {
+            mid[c] = 0.5 * (lo[c] + hi[c]);
+            done[c] = (mid[c] <= lo[c]) || (mid[c] >= hi[c]) ||
+                      (hi[c] - lo[c] <= 2.0 * eps * fmax(fabs(lo[c]), fabs(hi[c])) + 1e-300);
+            alld = alld && done[c];
+        }
+        if (__syncthreads_and(alld)) break;
+        int cnt[EPT];
+        sturm_counts3(de, np, mid, cnt);
+#pragma unroll
+        for (int c = 0; c < EPT; ++c) {
+            if (!done[c]) {
+                if (cnt[c] > mbase + 256 * c) hi[c] = mid[c]; else lo[c] = mid[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < EPT; ++c) {
+        const int m = mbase + 256 * c;
+        if (m < n) wall[ch * (size_t)ldw + m] = 0.5 * (lo[c] + hi[c]) * isc;
+    }
+}
+
 // One eigenvalue (index m, 0-based, ascending) of one tridiagonal matrix by MULTISECTION on one wavefront: every round
 // the 64 lanes count at 64 interior points of the bracket, which shrinks 65-fold (about ten rounds instead of 56
 // bisections).  Used to start the inverse iteration for the eigenvector the reference consumes (Hij(:, n0_ini) of
@@ -329,14 +483,16 @@ int launch_bisect_one(int n, const double *d_d, const double *d_e, int m, double
 int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_e, double *d_w, long ldw,
                   hipStream_t st)
 {
-    const size_t lds = (size_t)2 * (n + 3 * RS) * sizeof(double);
+    const size_t lds = (size_t)2 * (n + 3 * RS + HW) * sizeof(double) + 256 * EPT * sizeof(int);
     if (lds > 150 * 1024) return BSP_ERR_UNSUPPORTED;
     static bool attr_set = false;
-    static int variant = 2;
+    static int variant = 3;
     if (!attr_set) {
         BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect2_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect3_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         const char *e = getenv("BSP_BISECT");
         if (e) variant = atoi(e);
@@ -344,7 +500,8 @@ int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_
     }
     const dim3 grid((n + 256 * EPT - 1) / (256 * EPT), batch);
     if (variant == 1) hipLaunchKernelGGL(bisect_kernel, grid, dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
-    else hipLaunchKernelGGL(bisect2_kernel, grid, dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
+    else if (variant == 2) hipLaunchKernelGGL(bisect2_kernel, grid, dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
+    else hipLaunchKernelGGL(bisect3_kernel, grid, dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }
