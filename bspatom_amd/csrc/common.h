@@ -46,6 +46,11 @@ struct GemmDesc {
     int ksplit;       // gemm_kernel: > 1 = split-K, grid.z = batch * ksplit, slice s covers k in [s*kchunk, (s+1)*kchunk)
     int kchunk;       //              and writes alpha * partial to C + s*bCs (beta ignored); set by gemm_splitk_f64
     long bCs;
+    // gemm2 MODE 1: the valid tiles are enumerated in 8 x 8 super-blocks; entry s = super-block (sbx, sby) in tile
+    // units / 8, sbpre = number of valid tiles up to and including it (set by syr2k_lower_f64)
+    int nsb;
+    unsigned short sbpre[56];
+    unsigned char sbx[56], sby[56];
 };
 int gemm_f64(const GemmDesc &g, hipStream_t st);
 // C = alpha * A B + beta * C with the K range cut into `splits` slices that run as separate workgroups (for products

@@ -385,15 +385,22 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmDesc g)
         bz = xcd + 8 * zi;
         if (bz >= g.batch) return;
         const int ylo = g.yoff, part1 = (g.yoff == 0 && T == nb);       // part 1 of the look-ahead: by == 0 only
-        bx = 0;
+        // Within a channel the tiles go in 8 x 8 SUPER-BLOCKS (row-major inside): the 64 workgroups an XCD holds at a
+        // time then share 8 row slices and 8 column slices of the [V|Z|V] panels (2 MB, L2-resident) instead of one
+        // row slice and up to 32 column slices that each serve a single tile before the streaming C tiles evict them.
+        int sb = 0;
+        while (t >= (int)g.sbpre[sb]) ++sb;
+        if (sb) t -= (int)g.sbpre[sb - 1];
+        const int sy0 = 8 * (int)g.sby[sb];
+        bx = 8 * (int)g.sbx[sb];
         for (;;) {
             const int yhi = part1 ? 0 : ((bx + 1 < nb - 1) ? bx + 1 : nb - 1);
-            const int c = yhi - ylo + 1;
-            if (c > 0 && t < c) break;
+            const int lo = (ylo > sy0) ? ylo : sy0, hi = (yhi < sy0 + 7) ? yhi : sy0 + 7;
+            const int c = hi - lo + 1;
+            if (c > 0 && t < c) { by = lo + t; break; }
             if (c > 0) t -= c;
             ++bx;
         }
-        by = ylo + t;
     }
     if (MODE == 2) {
         // same XCD-aware layout for the SYMM-shaped product: all row tiles of a channel on one XCD, so that W (and
@@ -504,14 +511,25 @@ int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const doub
     g.C = A22; g.sCm = ld; g.sCn = 1; g.bC = bsA;                     // C'(c, r) = A22(r, c)
     g.alpha = -1.0; g.beta = 1.0;
     const int nb = (m + 127) / 128;
-    // valid tiles per channel: row block bx holds column blocks ylo .. min(bx + 1, nb - 1)  (part 1: column block 0 only)
+    // valid tiles per channel: row block bx holds column blocks ylo .. min(bx + 1, nb - 1)  (part 1: column block 0 only),
+    // enumerated in 8 x 8 super-blocks (see the kernel)
     int T = 0;
     g.yoff = (part == 2) ? 1 : 0;
-    if (part == 1) T = nb;
-    else
-        for (int bx = 0; bx < nb; ++bx) {
-            const int c = ((bx + 1 < nb - 1) ? bx + 1 : nb - 1) - g.yoff + 1;
-            if (c > 0) T += c;
+    const int nsx = (nb + 7) / 8;
+    if (nsx * (nsx + 1) / 2 + nsx > 56) return BSP_ERR_UNSUPPORTED;
+    g.nsb = 0;
+    for (int sx = 0; sx < nsx; ++sx)
+        for (int sy = 0; sy <= ((sx + 1 < nsx - 1) ? sx + 1 : nsx - 1); ++sy) {
+            int c = 0;
+            for (int bx = 8 * sx; bx < 8 * sx + 8 && bx < nb; ++bx) {
+                const int yhi = (part == 1) ? 0 : ((bx + 1 < nb - 1) ? bx + 1 : nb - 1);
+                const int lo = (g.yoff > 8 * sy) ? g.yoff : 8 * sy, hi = (yhi < 8 * sy + 7) ? yhi : 8 * sy + 7;
+                if (hi >= lo) c += hi - lo + 1;
+            }
+            if (c == 0) continue;
+            T += c;
+            g.sbx[g.nsb] = (unsigned char)sx; g.sby[g.nsb] = (unsigned char)sy; g.sbpre[g.nsb] = (unsigned short)T;
+            ++g.nsb;
         }
     if (T <= 0) return BSP_OK;
     g.lower_only = T;                                                 // MODE 1 reads it as the tile count
