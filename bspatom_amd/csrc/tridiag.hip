@@ -251,7 +251,13 @@ __global__ __launch_bounds__(256) void bisect2_kernel(int n, int ldn, const doub
 //     evaluation round and every eigenvalue starts from the grid cell that brackets it -- ten bisection levels for
 //     the price of one; the search keeps the invariant count(lo) <= m < count(hi) and therefore needs no
 //     monotonicity of the computed counts.
+//   * the bracket of an eigenvalue is final when it is narrower than 2 eps |x| OR eps/16 of the matrix norm (2^-56 in the
+//     scaled units): T comes out of two orthogonal reductions with errors of order eps |T|, so digits below that
+//     are noise (LAPACK's dstebz stops at 2 ulp |T|, 32 times earlier).  Without the absolute floor the eigenvalues
+//     next to zero (|E| ~ 1e-8 |T| for the states at the ionisation threshold) need 25 more levels than the rest, and
+//     the workgroup that holds them decides the duration of the launch.
 constexpr int HW = 32;     // rows per sign-history word (np is padded to a multiple of it)
+constexpr double ABSTOL3 = 1.3877787807814457e-17;   // 2^-56
 
 __device__ __forceinline__ void sturm_counts3(const double2 *__restrict__ de, int np, const double (&x)[EPT], int (&cnt)[EPT])
 {
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(256) void bisect3_kernel(int n, int ldn, const doub
         for (int c = 0; c < EPT; ++c) {
             mid[c] = 0.5 * (lo[c] + hi[c]);
             done[c] = (mid[c] <= lo[c]) || (mid[c] >= hi[c]) ||
-                      (hi[c] - lo[c] <= 2.0 * eps * fmax(fabs(lo[c]), fabs(hi[c])) + 1e-300);
+                      (hi[c] - lo[c] <= fmax(2.0 * eps * fmax(fabs(lo[c]), fabs(hi[c])), ABSTOL3));
             alld = alld && done[c];
         }
         if (__syncthreads_and(alld)) break;
