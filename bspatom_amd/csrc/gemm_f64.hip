@@ -359,9 +359,36 @@ __device__ __forceinline__ void tile_store(const double2 (&r)[BK * BX / 512], do
     }
 }
 
+// The same staging with everything that does not change from K-step to K-step taken out of the loop: per thread
+// the BYTE offset of each of its double2 elements relative to the operand's position at k0 (32 bits: an operand of
+// sy2sb spans < 4 GB), so that a K-step's loads are `global_load_dwordx4 v, voffset, s[base]` with a uniform base
+// that advances by a constant -- no 64-bit multiplies, no bounds branches in the loop (the kernels built on this
+// spent ~250 instructions per K-step beside their 32-64 MFMAs).  Rows beyond X are CLAMPED instead of zero-filled:
+// such a row only feeds output rows that are never stored (callers guarantee K % BK == 0, X even).  Used by MODE 2
+// (symm: 132.8 -> 120.4 ms standalone).  MODE 1 keeps the plain form: with the offsets hoisted the compiler parks
+// the staging registers in scratch around the MFMA block (236 ms), and staging through LDS-DMA loads instead
+// (global_load_lds_dwordx4, no staging registers at all) measured 148 against 145.5 ms.
+template <int BX, int LAY>
+__device__ __forceinline__ void tile_offsets(unsigned (&off)[BK * BX / 512], long sx, long sk, int x0, int X, int tid)
+{
+#pragma unroll
+    for (int it = 0; it < BK * BX / 512; ++it) {
+        const int idx = tid + it * 256;
+        if (LAY == 0) {
+            const int kk = idx / (BX / 2), xx = (idx % (BX / 2)) * 2;
+            int gx = x0 + xx; gx = (gx + 1 < X) ? gx : X - 2;
+            off[it] = (unsigned)(((long)gx + (long)kk * sk) * 8);
+        } else {
+            const int xx = idx / (BK / 2), kk = (idx % (BK / 2)) * 2;
+            int gx = x0 + xx; gx = (gx < X) ? gx : X - 1;
+            off[it] = (unsigned)(((long)gx * sx + (long)kk) * 8);
+        }
+    }
+}
+
 // kernel view: C'(i', j') with j' memory-contiguous (sCn == 1 required).
 template <int BM, int BN, int ALAY, int BLAY, int MODE, int DIAGG = 0>
-__global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmDesc g)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm2_kernel(GemmDesc g)
 {
     long long dacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tl = DIAGG ? (long long)__builtin_amdgcn_s_memtime() : 0;
@@ -418,19 +445,48 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmDesc g)
     double *C = g.C + (long)bz * g.bC;
     const double alpha = g.alpha, beta = g.beta;
 
+    const int nk = (g.K + BK - 1) / BK;
     double2 ra[BK * BM / 512], rb[BK * BN / 512];
+    double2 ra1[(MODE == 2) ? BK * BM / 512 : 1], rb1[(MODE == 2) ? BK * BN / 512 : 1];   // MODE 2: second staging set
     // MODE 2: B is the symmetric A22; K-steps beyond the diagonal block of this row tile read A22^T
     const int ksw = (MODE == 2) ? (n0 + 128) : 0x7fffffff;
-    auto loadB = [&](int k0) {
-        if (MODE == 2 && k0 >= ksw) tile_load<BN, 1>(rb, B, g.sBk, 1, n0, k0, g.N, g.K, tid);   // A22(k,i): stride ld along i
-        else tile_load<BN, BLAY>(rb, B, g.sBn, g.sBk, n0, k0, g.N, g.K, tid);
-    };
-    auto storeB = [&](int k0, double *S) {
-        if (MODE == 2 && k0 >= ksw) tile_store<BN, 1>(rb, S, tid);
-        else tile_store<BN, BLAY>(rb, S, tid);
-    };
-    tile_load<BM, ALAY>(ra, A, g.sAm, g.sAk, m0, 0, g.M, g.K, tid);
-    loadB(0);
+    constexpr int NRA = BK * BM / 512, NRB = BK * BN / 512;
+    unsigned offA[NRA], offB[NRB], offT[NRB];
+    tile_offsets<BM, ALAY>(offA, g.sAm, g.sAk, m0, g.M, tid);
+    tile_offsets<BN, BLAY>(offB, g.sBn, g.sBk, n0, g.N, tid);
+    if (MODE == 2) tile_offsets<BN, 1>(offT, g.sBk, 1, n0, g.N, tid);                             // A22(k,i): stride ld along i
+    const long ksA = (ALAY == 0) ? g.sAk * 8 : 8, ksB = (BLAY == 0) ? g.sBk * 8 : 8;           // bytes per unit of k
+#define G2_LOAD_A(k0_, ra)                                                                                    \
+    {                                                                                                        \
+        const char *kb_ = reinterpret_cast<const char *>(A) + (long)(k0_) * ksA;                             \
+        _Pragma("unroll") for (int it = 0; it < NRA; ++it) ra[it] = *reinterpret_cast<const double2 *>(kb_ + offA[it]); \
+    }
+#define G2_LOAD_B(k0_, rb)                                                                                    \
+    {                                                                                                        \
+        if (MODE == 2 && (k0_) >= ksw) {                                                                     \
+            const char *kb_ = reinterpret_cast<const char *>(B) + (long)(k0_) * 8;                           \
+            _Pragma("unroll") for (int it = 0; it < NRB; ++it) rb[it] = *reinterpret_cast<const double2 *>(kb_ + offT[it]); \
+        } else {                                                                                             \
+            const char *kb_ = reinterpret_cast<const char *>(B) + (long)(k0_) * ksB;                         \
+            _Pragma("unroll") for (int it = 0; it < NRB; ++it) rb[it] = *reinterpret_cast<const double2 *>(kb_ + offB[it]); \
+        }                                                                                                    \
+    }
+#define G2_STORE_B(k0_, S_, rb)                                              \
+    {                                                                        \
+        if (MODE == 2 && (k0_) >= ksw) tile_store<BN, 1>(rb, S_, tid);       \
+        else tile_store<BN, BLAY>(rb, S_, tid);                              \
+    }
+    if (MODE == 1) {
+        tile_load<BM, ALAY>(ra, A, g.sAm, g.sAk, m0, 0, g.M, g.K, tid);
+        tile_load<BN, BLAY>(rb, B, g.sBn, g.sBk, n0, 0, g.N, g.K, tid);
+    } else {
+        G2_LOAD_A(0, ra)
+        G2_LOAD_B(0, rb)
+        if (nk > 1) {                                  // MODE 2 prefetches two K-steps ahead (second register set)
+            G2_LOAD_A(BK, ra1)
+            G2_LOAD_B(BK, rb1)
+        }
+    }
 
     double4_t acc[TM][TN];
     if (beta != 0.0) {
@@ -456,31 +512,64 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmDesc g)
     G2_STAMP(0)                                              // C, first A/B tiles: loads issued
     if (DIAGG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); G2_STAMP(1) }   // ... and arrived
     tile_store<BM, ALAY>(ra, As[0], tid);
-    storeB(0, Bs[0]);
+    G2_STORE_B(0, Bs[0], rb)
     lds_barrier2();
     G2_STAMP(2)
 
-    const int nk = (g.K + BK - 1) / BK;
+    if constexpr (MODE == 2) {
+        // Two K-steps of prefetch: while tile t is multiplied, tile t+1 is in flight or in registers (set S1) and the
+        // loads of tile t+2 are issued into the set tile t just left (S0); a K-step here is only 32 MFMAs per wave
+        // (0.85 us), less than the memory latency under load, so one step of distance left a wait in every step.
+#define G2_STEP2(t_, S0a, S0b, S1a, S1b)                                                                     \
+        {                                                                                                    \
+            const int cur = (t_) & 1;                                                                        \
+            if ((t_) + 2 < nk) {                                                                             \
+                G2_LOAD_A(((t_) + 2) * BK, S0a)                                                              \
+                G2_LOAD_B(((t_) + 2) * BK, S0b)                                                              \
+            }                                                                                                \
+            _Pragma("unroll") for (int k4 = 0; k4 < BK / 4; ++k4) {                                          \
+                const int kr = k4 * 4 + (lane >> 4);                                                         \
+                mfma_step<TM, TN>(&As[cur][kr * LDA + wm * (BM / WM)], &Bs[cur][kr * LDB + wn * (BN / WN)], lane, acc); \
+            }                                                                                                \
+            if ((t_) + 1 < nk) {                                                                             \
+                tile_store<BM, ALAY>(S1a, As[cur ^ 1], tid);                                                 \
+                G2_STORE_B(((t_) + 1) * BK, Bs[cur ^ 1], S1b)                                                \
+            }                                                                                                \
+            lds_barrier2();                                                                                  \
+        }
+        int t = 0;
+        for (; t + 1 < nk; t += 2) {
+            G2_STEP2(t, ra, rb, ra1, rb1)
+            G2_STEP2(t + 1, ra1, rb1, ra, rb)
+        }
+        if (t < nk) G2_STEP2(t, ra, rb, ra1, rb1)
+    } else {
     for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) {
-            tile_load<BM, ALAY>(ra, A, g.sAm, g.sAk, m0, (t + 1) * BK, g.M, g.K, tid);
-            loadB((t + 1) * BK);
+            const int cur = t & 1;
+            if (t + 1 < nk) {
+                if (MODE == 1) {
+                    tile_load<BM, ALAY>(ra, A, g.sAm, g.sAk, m0, (t + 1) * BK, g.M, g.K, tid);
+                    tile_load<BN, BLAY>(rb, B, g.sBn, g.sBk, n0, (t + 1) * BK, g.N, g.K, tid);
+                } else {
+                    G2_LOAD_A((t + 1) * BK, ra)
+                    G2_LOAD_B((t + 1) * BK, rb)
+                }
+            }
+    #pragma unroll
+            for (int k4 = 0; k4 < BK / 4; ++k4) {
+                const int kr = k4 * 4 + (lane >> 4);
+                mfma_step<TM, TN>(&As[cur][kr * LDA + wm * (BM / WM)], &Bs[cur][kr * LDB + wn * (BN / WN)], lane, acc);
+            }
+            G2_STAMP(3)                                          // MFMAs of this k-tile (and issue of the next loads)
+            if (t + 1 < nk) {
+                if (DIAGG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); G2_STAMP(4) }   // wait for the next tile
+                tile_store<BM, ALAY>(ra, As[cur ^ 1], tid);
+                G2_STORE_B((t + 1) * BK, Bs[cur ^ 1], rb)
+            }
+            lds_barrier2();
+            G2_STAMP(5)
         }
-#pragma unroll
-        for (int k4 = 0; k4 < BK / 4; ++k4) {
-            const int kr = k4 * 4 + (lane >> 4);
-            mfma_step<TM, TN>(&As[cur][kr * LDA + wm * (BM / WM)], &Bs[cur][kr * LDB + wn * (BN / WN)], lane, acc);
-        }
-        G2_STAMP(3)                                          // MFMAs of this k-tile (and issue of the next loads)
-        if (t + 1 < nk) {
-            if (DIAGG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); G2_STAMP(4) }   // wait for the next tile
-            tile_store<BM, ALAY>(ra, As[cur ^ 1], tid);
-            storeB((t + 1) * BK, Bs[cur ^ 1]);
-        }
-        lds_barrier2();
-        G2_STAMP(5)
-    }
+}
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
