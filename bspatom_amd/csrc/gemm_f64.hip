@@ -489,7 +489,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 
     double4_t acc[TM][TN];
-    if (beta != 0.0) {
+    // a wave's sub-tile is either completely inside C or (the last tile of an odd number of 64-blocks) completely
+    // outside in one direction: the C accesses of the inside case need no per-element bounds branch and share 4 TM
+    // row pointers (row (lane >> 4) + 4 r + 16 i, column offsets 128 j bytes as immediates)
+    const int wr0 = m0 + wm * (BM / WM), wc0 = n0 + wn * (BN / WN);
+    const bool inside = (wr0 + BM / WM <= g.M) && (wc0 + BN / WN <= g.N);
+    double *Cl = C + (long)(wr0 + (lane >> 4)) * g.sCm + (long)(wc0 + (lane & 15));
+    if (beta != 0.0 && inside) {
+        const double sc = beta / alpha;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double *pr = Cl + (long)(16 * i + 4 * r) * g.sCm;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j][r] = sc * pr[16 * j];
+            }
+    } else if (beta != 0.0) {
         const double sc = beta / alpha;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -570,16 +586,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             G2_STAMP(5)
         }
 }
+    if (inside) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gi = m0 + wm * (BM / WM) + i * 16 + (lane >> 4) + 4 * r;
-                const int gj = n0 + wn * (BN / WN) + j * 16 + (lane & 15);
-                if (gi < g.M && gj < g.N) C[(long)gi * g.sCm + (long)gj] = alpha * acc[i][j][r];
+                double *pr = Cl + (long)(16 * i + 4 * r) * g.sCm;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) pr[16 * j] = alpha * acc[i][j][r];
             }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gi = m0 + wm * (BM / WM) + i * 16 + (lane >> 4) + 4 * r;
+                    const int gj = n0 + wn * (BN / WN) + j * 16 + (lane & 15);
+                    if (gi < g.M && gj < g.N) C[(long)gi * g.sCm + (long)gj] = alpha * acc[i][j][r];
+                }
+    }
     G2_STAMP(6)
     if (DIAGG) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
