@@ -511,7 +511,9 @@ __global__ __launch_bounds__(64) void form_T_kernel(const double *__restrict__ G
     // Thread i owns row i of T.  Column j needs s_i = sum_{p=i}^{j-1} T(i,p) G(p,j); T is upper triangular and its
     // columns >= j are still zero, so the sum may run over ALL p: a fixed trip count, four independent accumulators
     // and 16-byte LDS reads (row i of T and row j of G^T are contiguous) instead of a dependent chain of single reads
-    // with data-dependent bounds (the first version: 200 us per panel, on the critical chain of the stage).
+    // with data-dependent bounds (the first version: 200 us per panel, on the critical chain of the stage).  Unrolling is
+    // limited on purpose: fully unrolled the kernel needed 268 registers, i.e. a completely empty SIMD, and waited
+    // for one behind the other pipelines' GEMM workgroups (82 now: it fits the place one GEMM workgroup leaves).
     __shared__ __attribute__((aligned(16))) double T[NB][NB + 2];
     __shared__ __attribute__((aligned(16))) double Gt[NB][NB + 2];       // Gt[j][p] = G(p, j)
     const int i = threadIdx.x;
@@ -519,11 +521,14 @@ __global__ __launch_bounds__(64) void form_T_kernel(const double *__restrict__ G
     const double *Gg = Gall + ch * NB * NB;
     const double *tau = tauall + ch * NB;
     double *Tg = Tall + ch * NB * NB;
+#pragma unroll 8
     for (int j = 0; j < NB; ++j) { Gt[j][i] = Gg[i * NB + j]; T[i][j] = 0.0; }
+    const double tau_l = tau[i];                           // tau_j is broadcast from lane j: no memory access in the column loop
     __syncthreads();
+#pragma unroll 1
     for (int j = 0; j < NB; ++j) {
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
+#pragma unroll 4
         for (int p = 0; p < NB; p += 4) {
             const double2 t01 = *reinterpret_cast<const double2 *>(&T[i][p]);
             const double2 t23 = *reinterpret_cast<const double2 *>(&T[i][p + 2]);
@@ -531,12 +536,13 @@ __global__ __launch_bounds__(64) void form_T_kernel(const double *__restrict__ G
             const double2 g23 = *reinterpret_cast<const double2 *>(&Gt[j][p + 2]);
             s0 += t01.x * g01.x; s1 += t01.y * g01.y; s2 += t23.x * g23.x; s3 += t23.y * g23.y;
         }
-        const double tj = tau[j];
+        const double tj = __shfl(tau_l, j);
         __syncthreads();
         if (i < j) T[i][j] = -tj * ((s0 + s1) + (s2 + s3));
         if (i == j) T[i][j] = tj;
         __syncthreads();
     }
+#pragma unroll 8
     for (int j = 0; j < NB; ++j) Tg[i + j * NB] = T[i][j];
 }
 
