@@ -193,6 +193,38 @@ def test_bisect(n, batch):
         assert err < 1e-13      # scipy (LAPACK QL) itself carries O(n eps |T|) error
 
 
+def test_bisect_edge_cases():
+    """The shapes the counting kernel special-cases: n = 1, 2, 33 (padding to 32-row history words), the zero matrix,
+    a multiple eigenvalue (every bracket of the first-level grid search lands in the same cell), a split matrix with
+    exact zeros on the off-diagonal, eigenvalues 1e-12 of the norm next to zero (the absolute floor eps/16 |T| of
+    the stopping rule applies: error <= eps |T|), and a graded matrix spanning 12 decades."""
+    from scipy.linalg import eigvalsh_tridiagonal
+    rng = np.random.default_rng(7)
+    cases = []
+    cases.append(("n1", np.array([[3.5]]), np.zeros((1, 0))))
+    cases.append(("n2", np.array([[1.0, -2.0]]), np.array([[0.5]])))
+    cases.append(("n33", rng.standard_normal((2, 33)), rng.standard_normal((2, 32))))
+    cases.append(("zero", np.zeros((1, 40)), np.zeros((1, 39))))
+    cases.append(("identity", np.ones((1, 100)) * 2.5, np.zeros((1, 99))))
+    d = rng.standard_normal((1, 200)); e = rng.standard_normal((1, 199)); e[0, ::7] = 0.0
+    cases.append(("split", d, e))
+    d = np.concatenate([np.full(50, 1e3), 1e-9 * rng.standard_normal(50)])[None, :]; e = np.concatenate([np.full(49, 1.0), [0.0], 1e-10 * np.ones(49)])[None, :]
+    cases.append(("tiny_next_to_zero", d, e))
+    d = (10.0 ** np.linspace(-6, 6, 97))[None, :]; e = (1e-3 * np.sqrt(d[0, :-1] * d[0, 1:]))[None, :]
+    cases.append(("graded", d, e))
+    for name, d, e in cases:
+        w = capi.stage_bisect(np.ascontiguousarray(d), np.ascontiguousarray(e))
+        for b in range(d.shape[0]):
+            n = d.shape[1]
+            ref = np.array([d[b, 0]]) if n == 1 else eigvalsh_tridiagonal(d[b], e[b])
+            tn = np.max(np.abs(ref))
+            if tn == 0.0: tn = 1.0                   # the zero matrix is treated as norm 1 (bracket +- 2.1 eps n)
+            err = np.max(np.abs(w[b] - ref)) / tn
+            note("bisect edge %s err %.2e" % (name, err))
+            assert np.all(np.diff(w[b]) >= 0), name
+            assert err <= 8 * np.finfo(float).eps * max(1, np.sqrt(n)), (name, err)
+
+
 # ---- SURVEY 8(f).2: dipole matrices accumulated in MATRIX_SVT's quadrature loop -----------------------------
 DIPOLE_CASES = ["dip_len_lin", "dip_vel_lin", "dip_len_exp", "dip_vel_exp"]
 
