@@ -117,6 +117,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libbspatom has no CPU path")
     torch.cuda.set_device(local)
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # launched by torch.distributed.run
+    # rank 0 prints ONE line on stdout: RCCL writes its banner (version, hostname, library path) to stdout when the
+    # communicator is created, so everything but the result line goes to stderr
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
@@ -212,7 +217,8 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_nfun, args.k)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
