@@ -307,17 +307,21 @@ static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, dou
         if ((rc = ensure_vec_scratch(p))) return rc;
         p->pre_ch = tl - l0;                               // member: must outlive the asynchronous copy
         const int ch = p->pre_ch;
-        BSP_HIP(hipStreamWaitEvent(p->st2, p->ev[4], 0));
-        BSP_HIP(hipMemcpyAsync(p->d_chan, &p->pre_ch, sizeof(int), hipMemcpyHostToDevice, p->st2));
-        BSP_HIP(hipMemsetAsync(p->d_pinfo, 0, sizeof(int), p->st2));
-        if ((rc = launch_bisect_one(n, p->d_d + (size_t)ch * np, p->d_e + (size_t)ch * np, tn0 - 1, p->d_pE, p->st2))) return rc;
+        // The eigenvalue first, ALONE on the main stream (one workgroup, six multisection rounds: ~1 ms on the idle
+        // GPU; beside the batched bisection it ran 7-13 ms, sharing a CU or waiting for one), then the inverse
+        // iteration on the side stream beside the batched bisection -- the batched kernel leaves LDS for it when it
+        // runs eight eigenvalues per thread (launch_bisect).  Kernel trace before: spectra at +16 ms after the bulge
+        // chasing, eigenvector at +30 ms.
+        BSP_HIP(hipMemcpyAsync(p->d_chan, &p->pre_ch, sizeof(int), hipMemcpyHostToDevice, p->st));
+        BSP_HIP(hipMemsetAsync(p->d_pinfo, 0, sizeof(int), p->st));
+        if ((rc = launch_bisect_one(n, p->d_d + (size_t)ch * np, p->d_e + (size_t)ch * np, tn0 - 1, p->d_pE, p->st))) return rc;
+        BSP_HIP(hipEventRecord(p->evx, p->st));
+        BSP_HIP(hipStreamWaitEvent(p->st2, p->evx, 0));
         if ((rc = launch_inverse_iteration(n, h.k, 1, p->d_SB, p->d_HB, p->d_chan, p->d_pE, p->d_vwork, p->d_pvec,
                                            p->d_pinfo, p->st2))) return rc;
         BSP_HIP(hipEventRecord(p->evx, p->st2));
         p->pre_l = tl; p->pre_n0 = tn0;
     }
-    // the batched bisection is enqueued AFTER the one-wave kernels above: its 512 workgroups fill every CU's LDS
-    // for the whole 40 ms, a kernel that arrives later waits that long for a slot
     if ((rc = launch_bisect(n, np, nl, p->d_d, p->d_e, Eout, n, p->st))) return rc;
     BSP_HIP(hipEventRecord(p->ev[5], p->st));
     if (p->pre_l >= 0) BSP_HIP(hipStreamWaitEvent(p->st, p->evx, 0));

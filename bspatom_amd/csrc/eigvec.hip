@@ -27,12 +27,50 @@ __device__ __forceinline__ double pencil_entry(const double *__restrict__ SB, co
 }
 
 // work layout per vector: U[n][2b+1], L[n][b], ipiv[n] (as doubles), tmp[n]
+// wave reductions on the DPP path (a ds_bpermute butterfly costs an LDS round trip per level, and every one of the
+// n dependent steps of this kernel has a reduction in it)
+template <int CTRL>
+__device__ __forceinline__ double ev_dpp(double x)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, 0xf, 0xf, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, 0xf, 0xf, true);
+    return r.d;
+}
+__device__ __forceinline__ double ev_readlane(double x, int l)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_readlane(u.i[0], l);
+    r.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+    return r.d;
+}
+__device__ __forceinline__ double ev_wave_sum(double x)          // every lane gets the sum over the 64 lanes
+{
+    x += ev_dpp<0x111>(x); x += ev_dpp<0x112>(x); x += ev_dpp<0x114>(x); x += ev_dpp<0x118>(x);   // row_shr 1, 2, 4, 8 (zeros shift in)
+    return (ev_readlane(x, 15) + ev_readlane(x, 31)) + (ev_readlane(x, 47) + ev_readlane(x, 63));
+}
+__device__ __forceinline__ double ev_row0_max(double x)          // max over lanes 0..15 (x >= 0 there), uniform
+{
+    x = fmax(x, ev_dpp<0x111>(x)); x = fmax(x, ev_dpp<0x112>(x)); x = fmax(x, ev_dpp<0x114>(x)); x = fmax(x, ev_dpp<0x118>(x));
+    return ev_readlane(x, 15);
+}
+
+// The kernel is ONE wavefront walking n dependent steps: a step's synchronisation must not wait for the global stores
+// of the step before (U, L rows: fire and forget) -- __syncthreads() does (s_waitcnt vmcnt(0)), which put a memory
+// round trip into every column of the factorisation.
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ __launch_bounds__(64) void invit_kernel(int n, int k, const double *__restrict__ SB,
                                                   const double *__restrict__ HBall,
                                                   const int *__restrict__ chan, const double *__restrict__ Eall,
                                                   double *workall, double *vecall, int *info)
 {
     extern __shared__ double y[];                       // n doubles
+    // one wavefront on a chain of dependent steps, usually beside the batched bisection whose waves are pure VALU work:
+    // issue priority over them (19 ms beside that kernel without, 11 ms alone)
+    __builtin_amdgcn_s_setprio(3);
     __shared__ double Wd[EB_MAX + 1][EWC];
     __shared__ double xs[64];
     const int lane = threadIdx.x;
@@ -56,81 +94,142 @@ __global__ __launch_bounds__(64) void invit_kernel(int n, int k, const double *_
         const int r = idx / WC, cs = idx % WC;          // rows 0..b, columns 0..2b+1 at start
         Wd[r % NR][cs] = pencil_entry(SB, HB, n, b, E, r, cs);
     }
-    __syncthreads();
-    for (int j = 0; j < n; ++j) {
-        const int nrow = (n - 1 - j < b) ? (n - 1 - j) : b;       // rows below the pivot row
-        // pivot search over rows j .. j+nrow in column j
-        double av = -1.0; int ar = j;
-        if (lane <= nrow) av = fabs(Wd[(j + lane) % NR][j % WC]), ar = j + lane;
+    lds_sync();
+    // The row that enters the window at step j (row j+b+1) does not depend on the elimination: its entries are
+    // fetched PF steps at a time (one per lane and step), so that the memory latency is paid once per PF columns
+    // and not in every one of the n dependent steps (the kernel is one wavefront: 4.5 us per column before).
+    constexpr int PF = 8;
+    double pe[PF];
+    // Ring positions are kept incrementally (j mod NR, j mod WC and their sums with small offsets wrap at most once):
+    // NR = k and WC = 2k are not powers of two, and an integer division is ~20 instructions -- a dozen of them per
+    // column were most of this loop.  The element (t, cc) pairs a lane eliminates are fixed: computed once.
+    constexpr int EQ = (EB_MAX * 2 * EB_MAX + 63) / 64;     // lane's elements of the rank-1 update: idx = lane + 64 q
+    int et[EQ], ec[EQ];
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(av, off);
-            const int orr = __shfl_xor(ar, off);
-            if (ov > av || (ov == av && orr < ar)) { av = ov; ar = orr; }
-        }
-        const int p = ar;
-        if (p != j) {
-            for (int cs = lane; cs < WC; cs += 64) {
-                const double t1 = Wd[j % NR][cs];
-                Wd[j % NR][cs] = Wd[p % NR][cs];
-                Wd[p % NR][cs] = t1;
+    for (int q = 0; q < EQ; ++q) {
+        const int idx = lane + 64 * q;
+        et[q] = (idx < b * 2 * b) ? 1 + idx / (2 * b) : 0;   // 0: no element
+        ec[q] = 1 + idx % (2 * b);
+    }
+    auto wrapN = [&](int r) { return (r >= NR) ? r - NR : r; };
+    auto wrapW = [&](int c) { return (c >= WC) ? c - WC : c; };
+    int jN = 0, jW = 0;                                      // j mod NR, j mod WC
+    for (int j = 0; j < n; ++j) {
+        if ((j & (PF - 1)) == 0) {
+            int c0 = wrapW(jW + 1);                          // (ju + 1) mod WC for ju = j
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int ju = j + u, rn = ju + b + 1;
+                int dcs = lane - c0; dcs = (dcs < 0) ? dcs + WC : dcs;          // (lane - (ju+1) mod WC) mod WC for lane < WC
+                const int c = (ju + 1) + dcs;
+                pe[u] = (lane < WC && rn < n) ? pencil_entry(SB, HB, n, b, E, rn, c) : 0.0;
+                c0 = wrapW(c0 + 1);
             }
         }
-        __syncthreads();
-        double pv = Wd[j % NR][j % WC];
+        const int nrow = (n - 1 - j < b) ? (n - 1 - j) : b;       // rows below the pivot row
+        const int rl = wrapN(jN + ((lane <= b) ? lane : 0));       // ring row of matrix row j + lane (lane <= b)
+        // pivot search over rows j .. j+nrow in column j
+        // (rows j .. j+nrow sit in lanes 0 .. nrow <= 15: the first DPP row; ties go to the smallest row)
+        const double av = (lane <= nrow) ? fabs(Wd[rl][jW]) : 0.0;
+        const double mxv = ev_row0_max(av);
+        const unsigned long long hit = __ballot(lane <= nrow && av == mxv);
+        const int dp = hit ? (__ffsll((long long)hit) - 1) : 0;
+        const int p = j + dp;
+        if (dp != 0) {
+            const int pN = wrapN(jN + dp);
+            if (lane < WC) {
+                const double t1 = Wd[jN][lane];
+                Wd[jN][lane] = Wd[pN][lane];
+                Wd[pN][lane] = t1;
+            }
+        }
+        lds_sync();
+        double pv = Wd[jN][jW];
         if (fabs(pv) < pertol) pv = (pv < 0.0) ? -pertol : pertol;
         double lt = 0.0;
-        if (lane >= 1 && lane <= nrow) lt = Wd[(j + lane) % NR][j % WC] / pv;
-        __syncthreads();
-        if (lane == 0) { Wd[j % NR][j % WC] = pv; piv[j] = (double)p; }
-        if (lane >= 1 && lane <= nrow) Wd[(j + lane) % NR][j % WC] = 0.0;
+        const double rpv = 1.0 / pv;
+        if (lane >= 1 && lane <= nrow) lt = Wd[rl][jW] * rpv;
+        lds_sync();
+        if (lane == 0) { Wd[jN][jW] = pv; piv[j] = (double)p; }
+        if (lane >= 1 && lane <= nrow) Wd[rl][jW] = 0.0;
         if (lane >= 1 && lane <= b) Lm[(size_t)j * b + lane - 1] = lt;
         xs[lane] = lt;
-        __syncthreads();
+        lds_sync();
         // elimination: rows t = 1..nrow, columns cc = 1..2b
-        for (int idx = lane; idx < nrow * 2 * b; idx += 64) {
-            const int t = 1 + idx / (2 * b), cc = 1 + idx % (2 * b);
-            const int cs = (j + cc) % WC;
-            Wd[(j + t) % NR][cs] -= xs[t] * Wd[j % NR][cs];
+#pragma unroll
+        for (int q = 0; q < EQ; ++q) {
+            if (q * 64 < b * 2 * b) {                               // uniform: this k needs round q at all
+                const int t = et[q];
+                if (t >= 1 && t <= nrow) {
+                    const int cs = wrapW(jW + ec[q]);
+                    Wd[wrapN(jN + t)][cs] -= xs[t] * Wd[jN][cs];
+                }
+            }
         }
         // store U row j
-        for (int cc = lane; cc <= 2 * b; cc += 64) U[(size_t)j * (2 * b + 1) + cc] = Wd[j % NR][(j + cc) % WC];
-        __syncthreads();
+        if (lane <= 2 * b) U[(size_t)j * (2 * b + 1) + lane] = Wd[jN][wrapW(jW + lane)];
+        lds_sync();
         // slide the window: row j leaves, row j+b+1 enters (columns j+1 .. j+2b+1; slot of j cleared)
-        const int rn = j + b + 1;
-        for (int cs = lane; cs < WC; cs += 64) {
-            // absolute column that maps to slot cs within [j+1, j+2b+2)
-            int c = (j + 1) + ((cs - (j + 1) % WC) % WC + WC) % WC;
-            Wd[j % NR][cs] = (rn < n) ? pencil_entry(SB, HB, n, b, E, rn, c) : 0.0;
+        // (slot cs = lane holds the absolute column (j+1) + ((cs - (j+1) % WC) mod WC) of [j+1, j+2b+2))
+        {
+            double pv_ = pe[0];
+#pragma unroll
+            for (int u = 1; u < PF; ++u) pv_ = ((j & (PF - 1)) == u) ? pe[u] : pv_;
+            if (lane < WC) Wd[jN][lane] = pv_;
         }
-        __syncthreads();
+        lds_sync();
+        jN = wrapN(jN + 1); jW = wrapW(jW + 1);
     }
 
     // ---- inverse iteration: 3 solves ----
     for (int j = lane; j < n; j += 64) y[j] = 1.0;
-    __syncthreads();
+    __syncthreads();                                   // also: U, L, piv are in memory (vmcnt(0))
     for (int iter = 0; iter < 3; ++iter) {
         // forward: y <- L^-1 P y
-        for (int j = 0; j < n; ++j) {
-            const int p = (int)piv[j];
-            double yj;
-            if (p != j) {
-                if (lane == 0) { const double t1 = y[j]; y[j] = y[p]; y[p] = t1; }
-                __syncthreads();
+        for (int j0 = 0; j0 < n; j0 += PF) {
+            double lv[PF], pvv[PF];                      // multipliers and pivot rows of PF steps: independent of y
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int j = j0 + u;
+                lv[u] = (j < n && lane >= 1 && lane <= b) ? Lm[(size_t)j * b + lane - 1] : 0.0;
+                pvv[u] = (j < n) ? piv[j] : 0.0;
             }
-            yj = y[j];
-            const int nrow = (n - 1 - j < b) ? (n - 1 - j) : b;
-            if (lane >= 1 && lane <= nrow) y[j + lane] -= Lm[(size_t)j * b + lane - 1] * yj;
-            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int j = j0 + u;
+                if (j < n) {
+                    const int p = (int)pvv[u];
+                    if (p != j) {
+                        if (lane == 0) { const double t1 = y[j]; y[j] = y[p]; y[p] = t1; }
+                        lds_sync();
+                    }
+                    const double yj = y[j];
+                    const int nrow = (n - 1 - j < b) ? (n - 1 - j) : b;
+                    if (lane >= 1 && lane <= nrow) y[j + lane] -= lv[u] * yj;
+                    lds_sync();
+                }
+            }
         }
         // backward: x_j = (y_j - sum_{cc=1..2b} U[j][cc] x_{j+cc}) / U[j][0]
-        for (int j = n - 1; j >= 0; --j) {
-            double s = 0.0;
-            if (lane >= 1 && lane <= 2 * b && j + lane < n) s = U[(size_t)j * (2 * b + 1) + lane] * y[j + lane];
+        for (int j0 = n - 1; j0 >= 0; j0 -= PF) {
+            double uv[PF], ru[PF];                       // row j of U: lane cc holds U[j][cc]; 1 / U[j][0] for every lane
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-            if (lane == 0) y[j] = (y[j] - s) / U[(size_t)j * (2 * b + 1)];
-            __syncthreads();
+            for (int u = 0; u < PF; ++u) {
+                const int j = j0 - u;
+                uv[u] = (j >= 0 && lane >= 1 && lane <= 2 * b) ? U[(size_t)j * (2 * b + 1) + lane] : 0.0;
+                ru[u] = (j >= 0) ? 1.0 / U[(size_t)j * (2 * b + 1)] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int j = j0 - u;
+                if (j >= 0) {
+                    double s = 0.0;
+                    if (lane >= 1 && lane <= 2 * b && j + lane < n) s = uv[u] * y[j + lane];
+                    s = ev_wave_sum(s);
+                    if (lane == 0) y[j] = (y[j] - s) * ru[u];
+                    lds_sync();
+                }
+            }
         }
         // normalise by max-abs, then rhs = S x for the next iteration
         double mx = 0.0;
@@ -138,8 +237,19 @@ __global__ __launch_bounds__(64) void invit_kernel(int n, int k, const double *_
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
         const double sc = (mx > 0.0) ? 1.0 / mx : 1.0;
-        for (int j = lane; j < n; j += 64) { y[j] *= sc; tmp[j] = y[j]; }
+        // change against the previous iterate (tmp still holds it), up to sign: below 1e-12 of the max-norm after the
+        // SECOND solve the third is skipped (it costs a fifth of the kernel, which is a chain of n dependent steps
+        // per pass on one wavefront and the last thing the solve waits for)
+        double dp = 0.0, dm = 0.0;
+        for (int j = lane; j < n; j += 64) {
+            const double v = y[j] * sc;
+            if (iter == 1) { const double o = tmp[j]; dp = fmax(dp, fabs(v - o)); dm = fmax(dm, fabs(v + o)); }
+            y[j] = v; tmp[j] = v;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { dp = fmax(dp, __shfl_xor(dp, off)); dm = fmax(dm, __shfl_xor(dm, off)); }
         __syncthreads();
+        if (iter == 1 && fmin(dp, dm) <= 1e-12) break;
         if (iter < 2) {
             for (int j = lane; j < n; j += 64) {
                 double s = 0.0;
@@ -152,7 +262,7 @@ __global__ __launch_bounds__(64) void invit_kernel(int n, int k, const double *_
                 }
                 y[j] = s;
             }
-            __syncthreads();
+            lds_sync();
         }
     }
     // ---- S-normalise: c^T S c = 1, sign: first significant coefficient positive ----

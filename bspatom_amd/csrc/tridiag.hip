@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) void bisect2_kernel(int n, int ldn, const doub
 constexpr int HW = 32;     // rows per sign-history word (np is padded to a multiple of it)
 constexpr double ABSTOL3 = 1.3877787807814457e-17;   // 2^-56
 
+template <int EPT>
 __device__ __forceinline__ void sturm_counts3(const double2 *__restrict__ de, int np, const double (&x)[EPT], int (&cnt)[EPT])
 {
     double p0[EPT], p1[EPT];
@@ -301,6 +302,7 @@ __device__ __forceinline__ void sturm_counts3(const double2 *__restrict__ de, in
     }
 }
 
+template <int EPT>
 __global__ __launch_bounds__(256) void bisect3_kernel(int n, int ldn, const double *__restrict__ dall,
                                                      const double *__restrict__ eall, double *wall, long ldw)
 {
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(256) void bisect3_kernel(int n, int ldn, const doub
         int cc[EPT];
 #pragma unroll
         for (int c = 0; c < EPT; ++c) xg[c] = gl + w * ((double)(tid + 256 * c + 1) * (1.0 / (NG + 1)));
-        sturm_counts3(de, np, xg, cc);
+        sturm_counts3<EPT>(de, np, xg, cc);
 #pragma unroll
         for (int c = 0; c < EPT; ++c) cg[tid + 256 * c] = cc[c];
         __syncthreads();
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(256) void bisect3_kernel(int n, int ldn, const doub
         }
         if (__syncthreads_and(alld)) break;
         int cnt[EPT];
-        sturm_counts3(de, np, mid, cnt);
+        sturm_counts3<EPT>(de, np, mid, cnt);
 #pragma unroll
         for (int c = 0; c < EPT; ++c) {
             if (!done[c]) {
@@ -471,8 +473,92 @@ __global__ __launch_bounds__(64) void bisect_one_kernel(int n, const double *__r
     if (lane == 0) *out = 0.5 * (lo + hi) * isc;
 }
 
+// The same on a workgroup of 256 threads with the counting routine of bisect3_kernel: 1024 points per round (the
+// bracket shrinks 1025-fold: six rounds), four independent recurrences per thread.  The one-wave kernel above took
+// 12 ms next to the batched bisection (one dependent chain per lane, on a CU it shares); with the inverse iteration
+// behind it the consumed eigenvector arrived 15 ms after the spectra.
+__global__ __launch_bounds__(256) void bisect_one3_kernel(int n, const double *__restrict__ dg, const double *__restrict__ eg,
+                                                         int m, double *out)
+{
+    extern __shared__ double2 sde[];
+    constexpr int NG = 256 * EPT;
+    const int np = (n + HW - 1) / HW * HW;
+    double2 *de = sde;
+    int *cg = (int *)(sde + np + 1);
+    __shared__ double red[8];
+    const int tid = threadIdx.x;
+    double gl = 1e300, gu = -1e300;
+    for (int i = tid; i < n; i += 256) {
+        const double di = dg[i];
+        const double el = (i > 0) ? fabs(eg[i - 1]) : 0.0;
+        const double er = (i < n - 1) ? fabs(eg[i]) : 0.0;
+        gl = fmin(gl, di - el - er);
+        gu = fmax(gu, di + el + er);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        gl = fmin(gl, __shfl_xor(gl, off));
+        gu = fmax(gu, __shfl_xor(gu, off));
+    }
+    if ((tid & 63) == 0) { red[tid >> 6] = gl; red[4 + (tid >> 6)] = gu; }
+    __syncthreads();
+    gl = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+    gu = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+    const double eps = 2.220446049250313e-16;
+    double tnorm = fmax(fabs(gl), fabs(gu));
+    if (!(tnorm > 0.0)) tnorm = 1.0;
+    int kexp;
+    (void)frexp(tnorm, &kexp);
+    const double sc = ldexp(1.0, -kexp), isc = ldexp(1.0, kexp);
+    for (int i = tid; i <= np; i += 256) {
+        const double di = (i < n) ? dg[i] * sc : 2.0;
+        const double ev = (i >= 1 && i < n) ? (eg[i - 1] * sc) : 0.0;
+        de[i] = make_double2(di, fmax(ev * ev, 1e-60));
+    }
+    __syncthreads();
+    double lo = gl * sc - 2.1 * eps * n - 1e-300, hi = gu * sc + 2.1 * eps * n + 1e-300;
+    for (int round = 0; round < 16; ++round) {
+        const double w = hi - lo;
+        if (w <= fmax(2.0 * eps * fmax(fabs(lo), fabs(hi)), ABSTOL3)) break;
+        double x[EPT];
+        int cc[EPT];
+#pragma unroll
+        for (int c = 0; c < EPT; ++c) x[c] = lo + w * ((double)(tid + 256 * c + 1) * (1.0 / (NG + 1)));
+        sturm_counts3<EPT>(de, np, x, cc);
+#pragma unroll
+        for (int c = 0; c < EPT; ++c) cg[tid + 256 * c] = cc[c];
+        __syncthreads();
+        int L = -1, R = NG;                            // count(x_L) <= m < count(x_R); every thread does the same search
+        while (R - L > 1) {
+            const int mid = (L + R) >> 1;
+            if (cg[mid] > m) R = mid; else L = mid;
+        }
+        __syncthreads();                               // cg is rewritten in the next round
+        const double nlo = (L < 0) ? lo : lo + w * ((double)(L + 1) * (1.0 / (NG + 1)));
+        const double nhi = (R >= NG) ? hi : lo + w * ((double)(R + 1) * (1.0 / (NG + 1)));
+        if (!(nhi - nlo < w)) break;
+        lo = nlo; hi = nhi;
+    }
+    if (tid == 0) *out = 0.5 * (lo + hi) * isc;
+}
+
 int launch_bisect_one(int n, const double *d_d, const double *d_e, int m, double *d_out, hipStream_t st)
 {
+    static int variant1 = -1;
+    if (variant1 < 0) { const char *e = getenv("BSP_BISECT"); variant1 = e ? atoi(e) : 3; }
+    if (variant1 >= 3) {
+        const size_t lds3 = (size_t)2 * (n + 3 * RS + HW) * sizeof(double) + 256 * EPT * sizeof(int);
+        if (lds3 > 150 * 1024) return BSP_ERR_UNSUPPORTED;
+        static bool attr3 = false;
+        if (!attr3) {
+            BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect_one3_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr3 = true;
+        }
+        hipLaunchKernelGGL(bisect_one3_kernel, dim3(1), dim3(256), lds3, st, n, d_d, d_e, m, d_out);
+        BSP_HIP(hipGetLastError());
+        return BSP_OK;
+    }
     const size_t lds = (size_t)2 * (n + 3 * RS) * sizeof(double);
     if (lds > 150 * 1024) return BSP_ERR_UNSUPPORTED;
     static bool attr = false;
@@ -489,7 +575,13 @@ int launch_bisect_one(int n, const double *d_d, const double *d_e, int m, double
 int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_e, double *d_w, long ldw,
                   hipStream_t st)
 {
-    const size_t lds = (size_t)2 * (n + 3 * RS + HW) * sizeof(double) + 256 * EPT * sizeof(int);
+    // Eight eigenvalues per thread when that still fills the GPU (>= 256 workgroups): the same speed as four (measured
+    // 15.7 against 15.6 ms), but one workgroup per CU instead of two, so that half of every CU's LDS stays free
+    // for the one-wave kernels of the consumed eigenvector that run beside this one.
+    static int ept_env = -1;
+    if (ept_env < 0) { const char *e = getenv("BSP_BISECT_EPT"); ept_env = e ? atoi(e) : 0; }
+    const int ept3 = (ept_env == 4 || ept_env == 8) ? ept_env : ((((n + 2047) / 2048) * batch >= 256) ? 8 : 4);
+    const size_t lds = (size_t)2 * (n + 3 * RS + HW) * sizeof(double) + 256 * 8 * sizeof(int);
     if (lds > 150 * 1024) return BSP_ERR_UNSUPPORTED;
     static bool attr_set = false;
     static int variant = 3;
@@ -498,7 +590,9 @@ int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect2_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect3_kernel),
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect3_kernel<4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect3_kernel<8>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         const char *e = getenv("BSP_BISECT");
         if (e) variant = atoi(e);
@@ -507,7 +601,8 @@ int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_
     const dim3 grid((n + 256 * EPT - 1) / (256 * EPT), batch);
     if (variant == 1) hipLaunchKernelGGL(bisect_kernel, grid, dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
     else if (variant == 2) hipLaunchKernelGGL(bisect2_kernel, grid, dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
-    else hipLaunchKernelGGL(bisect3_kernel, grid, dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
+    else if (ept3 == 8) hipLaunchKernelGGL(bisect3_kernel<8>, dim3((n + 256 * 8 - 1) / (256 * 8), batch), dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
+    else hipLaunchKernelGGL(bisect3_kernel<4>, grid, dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }
