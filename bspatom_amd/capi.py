@@ -33,7 +33,7 @@ class Sizes(C.Structure):
 
 EXPORTS = ["bspatom_input_defaults", "bspatom_device_count", "bspatom_host_setup", "bspatom_problem_create", "bspatom_problem_destroy",
            "bspatom_problem_sizes", "bspatom_problem_grid", "bspatom_assemble", "bspatom_solve", "bspatom_solve_dev",
-           "bspatom_eigvec", "bspatom_eigvecs", "bspatom_dipole_bands", "bspatom_write_wf", "bspatom_last_timing", "bsp_dsygv_", "bspatom_stage_gemm",
+           "bspatom_eigvec", "bspatom_eigvecs", "bspatom_dipole_bands", "bspatom_dipole_elements", "bspatom_write_wf", "bspatom_last_timing", "bsp_dsygv_", "bspatom_stage_gemm",
            "bspatom_stage_standard_form", "bspatom_stage_sy2sb", "bspatom_stage_sb2st", "bspatom_stage_bisect"]
 
 _lib = None
@@ -60,6 +60,7 @@ def lib():
         L.bspatom_solve_dev.argtypes = [vp, i32, i32, vp, vp]
         L.bspatom_eigvec.argtypes = [vp, i32, i32, vp]
         L.bspatom_eigvecs.argtypes = [vp, i32, i32, i32, vp]
+        L.bspatom_dipole_elements.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
         L.bspatom_dipole_bands.argtypes = [vp, vp]
         L.bspatom_write_wf.argtypes = [vp, vp, i32, vp, vp]
         L.bspatom_last_timing.argtypes = [vp, vp]
@@ -165,6 +166,15 @@ class Problem:
         Z = np.zeros((count, self.nfun))
         _chk(lib().bspatom_eigvecs(self._h, l, n0, count, _p(Z)), "bspatom_eigvecs")
         return Z
+
+    def dipole_elements(self, l_ini, n0_ini, l_fin, n0_fin, count, a):
+        """D[i] = c(l_fin, n0_fin+i)^T (a[0] R_r + a[1] R_1/r + a[2] R_d/dr) c(l_ini, n0_ini), 1-based state numbers:
+        the DGEMV + DDOT of TRANS_AMP (PhotoIon.f90:95-107) for channels of the last solved batch."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.shape == (3,)
+        D = np.zeros(count)
+        _chk(lib().bspatom_dipole_elements(self._h, l_ini, n0_ini, l_fin, n0_fin, count, _p(a), _p(D)), "bspatom_dipole_elements")
+        return D
 
     def write_wf(self, c, npts=10000):
         c = np.ascontiguousarray(c, dtype=np.float64)

@@ -430,6 +430,59 @@ extern "C" int bspatom_eigvecs(bspatom_problem *p, int l, int n0, int count, dou
     return BSP_OK;
 }
 
+extern "C" int bspatom_dipole_elements(bspatom_problem *p, int l_ini, int n0_ini, int l_fin, int n0_fin, int count,
+                                       const double a[3], double *D)
+{
+    if (!p || !a || !D) return BSP_ERR_ARG;
+    const HostSetup &h = p->hs;
+    const int n = h.nfun;
+    const int lo = p->last_l0, hi = p->last_l0 + p->last_nl;
+    if (l_ini < lo || l_ini >= hi || l_fin < lo || l_fin >= hi || n0_ini < 1 || n0_ini > n || n0_fin < 1 || count < 1 ||
+        n0_fin + count - 1 > n) return BSP_ERR_ARG;
+    BSP_HIP(hipSetDevice(p->device));
+    int rc;
+    if (!p->ptab_ready) {
+        if ((rc = launch_point_table(h.nkp, h.k, h.ka, h.nfun, p->d_rt, p->d_aind, p->d_xg, p->d_wg, p->d_vpot,
+                                     p->d_ptab, p->d_left, p->d_status, p->st))) return rc;
+        p->ptab_ready = true;
+    }
+    const int chunk = count < 512 ? count : 512;
+    DevBuf RB, work, vec, ci, v, dD;
+    if ((rc = RB.alloc((size_t)3 * (2 * h.k - 1) * n)) || (rc = work.alloc((size_t)chunk * invit_work_doubles(n, h.k))) ||
+        (rc = vec.alloc((size_t)chunk * n)) || (rc = ci.alloc(n)) || (rc = v.alloc(n)) || (rc = dD.alloc(chunk))) return rc;
+    int *d_chan = nullptr;
+    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&d_chan), (size_t)chunk * sizeof(int)));
+    std::vector<int> hc(chunk, l_ini - lo);
+    hipError_t e = hipMemcpy(d_chan, hc.data(), sizeof(int), hipMemcpyHostToDevice);
+    // v = (a0 R_r + a1 R_1/r + a2 R_d/dr) c_ini
+    if (e == hipSuccess) e = hipMemsetAsync(p->d_info, 0, sizeof(int), p->st);
+    if (e == hipSuccess) {
+        rc = launch_dipole_bands(n, h.k, h.ka, h.nkp, p->d_ptab, p->d_left, RB.p, p->st);
+        if (!rc) rc = launch_inverse_iteration(n, h.k, 1, p->d_SB, p->d_HB, d_chan, p->d_E + (size_t)(l_ini - lo) * n + (n0_ini - 1),
+                                               work.p, ci.p, p->d_info, p->st);
+        if (!rc) rc = launch_band_apply(n, h.k, RB.p, a, ci.p, v.p, p->st);
+        if (!rc) e = hipStreamSynchronize(p->st);
+    }
+    // D(i) = c_fin(:, n0_fin + i) . v, the final states in chunks
+    if (e == hipSuccess && !rc) {
+        std::fill(hc.begin(), hc.end(), l_fin - lo);
+        e = hipMemcpy(d_chan, hc.data(), (size_t)chunk * sizeof(int), hipMemcpyHostToDevice);
+    }
+    for (int done = 0; e == hipSuccess && rc == BSP_OK && done < count; done += chunk) {
+        const int m = (count - done < chunk) ? count - done : chunk;
+        rc = launch_inverse_iteration(n, h.k, m, p->d_SB, p->d_HB, d_chan, p->d_E + (size_t)(l_fin - lo) * n + (n0_fin - 1 + done),
+                                      work.p, vec.p, p->d_info, p->st);
+        if (!rc) rc = launch_dots(n, m, vec.p, v.p, dD.p, p->st);
+        if (rc) break;
+        e = hipMemcpyAsync(D + done, dD.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, p->st);
+        if (e == hipSuccess) e = hipStreamSynchronize(p->st);
+    }
+    hipFree(d_chan);
+    if (rc) return rc;
+    BSP_HIP(e);
+    return check_status(p);
+}
+
 extern "C" int bspatom_write_wf(bspatom_problem *p, const double *c, int npts, double *r, double *u)
 {
     if (!p || !c || !r || !u || npts < 1) return BSP_ERR_ARG;

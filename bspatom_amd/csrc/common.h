@@ -115,6 +115,8 @@ int launch_inverse_iteration(int n, int k, int nvec, const double *d_SB, const d
                              const int *d_chan, const double *d_E, double *d_work, double *d_vec,
                              int *d_info, hipStream_t st);
 size_t invit_work_doubles(int n, int k);
+int launch_band_apply(int n, int k, const double *d_RB, const double a[3], const double *d_x, double *d_v, hipStream_t st);
+int launch_dots(int n, int m, const double *d_Z, const double *d_v, double *d_D, hipStream_t st);
 int launch_wf_tabulate(int nkp, int k, int n, const double *d_rt, const double *d_c, double ra,
                        double rb, int npts, double *d_r, double *d_u, int *d_status, hipStream_t st);
 

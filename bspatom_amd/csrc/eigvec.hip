@@ -311,6 +311,60 @@ int launch_inverse_iteration(int n, int k, int nvec, const double *d_SB, const d
     return BSP_OK;
 }
 
+// ---- dipole matrix elements between eigenvectors (TRANS_AMP, PhotoIon.f90:95-107) ----------------------------------
+// v = (a0 R_r + a1 R_{1/r} + a2 R_{d/dr}) x with the full bands RB[c][d + k - 1][i] = R_c(i, i + d) of assemble.hip
+// (the reference forms A(:,:) = c1 rij(:,:,1) + c2 rij(:,:,2) and calls DGEMV on the dense matrix; its zeros outside the
+// band contribute nothing).  One thread per row, diagonals in ascending column order.
+__global__ __launch_bounds__(256) void band_apply_kernel(int n, int k, const double *__restrict__ RB, double a0, double a1,
+                                                        double a2, const double *__restrict__ x, double *__restrict__ v)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t cs = (size_t)(2 * k - 1) * n;
+    double s = 0.0;
+    for (int d = -(k - 1); d <= k - 1; ++d) {
+        const int j = i + d;
+        if (j < 0 || j >= n) continue;
+        const size_t idx = (size_t)(d + k - 1) * n + i;
+        const double a = (a0 * RB[idx] + a1 * RB[cs + idx]) + a2 * RB[2 * cs + idx];
+        s += a * x[j];
+    }
+    v[i] = s;
+}
+
+// D[j] = Z[j][:] . v  (the DDOT of every final state): one workgroup per vector, strided partial sums and a fixed
+// reduction tree, so the result does not depend on timing
+__global__ __launch_bounds__(256) void dots_kernel(int n, const double *__restrict__ Z, const double *__restrict__ v,
+                                                  double *__restrict__ D)
+{
+    __shared__ double red[256];
+    const double *z = Z + (size_t)blockIdx.x * n;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += z[i] * v[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) D[blockIdx.x] = red[0];
+}
+
+int launch_band_apply(int n, int k, const double *d_RB, const double a[3], const double *d_x, double *d_v, hipStream_t st)
+{
+    hipLaunchKernelGGL(band_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, k, d_RB, a[0], a[1], a[2], d_x, d_v);
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
+
+int launch_dots(int n, int m, const double *d_Z, const double *d_v, double *d_D, hipStream_t st)
+{
+    if (m <= 0) return BSP_OK;
+    hipLaunchKernelGGL(dots_kernel, dim3(m), dim3(256), 0, st, n, d_Z, d_v, d_D);
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
+
 // ---- WRITE_WF (Bsp_Atom.f90:118-146): one thread per tabulation point ------------------------
 __global__ void wf_kernel(int nkp, int k, int n, const double *__restrict__ rt0, const double *__restrict__ c,
                           double ra, double rb, int npts, double *rout, double *uout, int *status)

@@ -217,3 +217,104 @@ def read_enl(path, lmax, emax_fin=-1.0):
                     n1_fin = ni
             n01[l] = (1, n1_fin, n0_fin)
     return nfun, E, n01
+
+
+# ---- KIND_PI = 1, 2: transition amplitudes of the one-photon (plane wave) branches ---------------------------------
+def three_j(j1, j2, j3, m1, m2, m3):
+    """Wigner 3j symbol, integer arguments: Racah's sum evaluated through log-factorials with the smallest exponent
+    taken out (what THREE_J does, Funs_WignerSymbols.for:1-62, so that the two agree to rounding)."""
+    if m1 + m2 + m3 != 0:
+        return 0.0
+    lf = [0.0]
+    for i in range(1, j1 + j2 + j3 + 2):
+        lf.append(lf[-1] + math.log(float(i)))          # lf[i] = log(i!)
+    zmin = max(0, j2 - j3 - m1, j1 + m2 - j3)
+    zmax = min(j1 + j2 - j3, j1 - m1, j2 + m2)
+    if zmax < zmin:
+        return 0.0
+    delta = 0.5 * (lf[j1 + j2 - j3] + lf[j3 + j1 - j2] + lf[j3 + j2 - j1] - lf[j1 + j2 + j3 + 1]
+                   + lf[j1 + m1] + lf[j1 - m1] + lf[j2 + m2] + lf[j2 - m2] + lf[j3 + m3] + lf[j3 - m3])
+    ex = [lf[z] + lf[j1 + j2 - j3 - z] + lf[j1 - m1 - z] + lf[j2 + m2 - z] + lf[j3 - j2 + m1 + z] + lf[j3 - j1 - m2 + z]
+          for z in range(zmin, zmax + 1)]
+    g = min(min(ex), 250.0)
+    acc = 0.0
+    for z, e in zip(range(zmin, zmax + 1), ex):
+        acc += (-1.0) ** z * math.exp(-(e - g))
+    return (-1.0) ** (j1 - j2 - m3) * math.exp(delta - g) * acc
+
+
+def final_channels(kind_pi, l0, m0):
+    """(l, m) of the final states SEL_LM selects for the dipolar cases (grid.f90:128-143): l0-1 (if it exists and can
+    carry m0) and l0+1, m unchanged; TRANS_AMP uses the LAST of them."""
+    out = []
+    for lf in (l0 - 1, l0 + 1):
+        if lf >= 0 and lf >= m0:
+            out.append((lf, m0))
+    return out
+
+
+def final_state_limits(E_fin, emax_fin):
+    """n0_fin, n1_fin (1-based) of SOLVE_SYSTEM for KIND_PI = 1, 2 at l = l_fin (matrices.f90:272-283) and the
+    Emax_fin it then uses (-1 means the largest eigenvalue)."""
+    n = len(E_fin)
+    if emax_fin == -1.0:
+        emax_fin = float(E_fin[n - 1])
+    n0 = -1; n1 = -1
+    for i in range(1, n + 1):
+        if E_fin[i - 1] < 0.0:
+            n0 = i
+        if E_fin[i - 1] <= emax_fin:
+            n1 = i
+    return min(n0 + 1, n - 1), n1, emax_fin
+
+
+def trans_amp(text, device=0):
+    """`Bsp_Atom.x < input` with KIND_PI = 1 (length gauge) or 2 (velocity gauge) up to the end of TRANS_AMP
+    (Bsp_Atom.f90:72-80; PhotoIon.f90:1-107): spectra of l = 0 .. lmax on the MI355X, the final-state window, and
+    T_fi(n) = An c0 <c_fin(n)| c1 rij1 + c2 rij2 |c_ini> with the dipole matrices of the same assembly pass.
+    Returns dict(E, l_fin, m_fin, n0_fin, n1_fin, T_fi, stdout).  The eigenvectors carry this library's sign
+    convention (LAPACK's is arbitrary), so T_fi(n) agrees with the reference up to the sign of each state.
+    CROSS_SECTIONS is not reproduced: the reference computes there with Enl(n0,l0), which it allocates for
+    KIND_PI >= 3 only (PhotoIon.f90:302)."""
+    import numpy as np
+    nl = read_namelists(text)
+    kind_pi = int(nl["vars_field"].get("kind_pi", 0))
+    if kind_pi not in (1, 2):
+        raise ValueError("trans_amp: KIND_PI must be 1 or 2")
+    mph = int(nl["vars_field"].get("mph", 0))
+    kw = {}
+    kw.update(nl["vars_bsp"]); kw.update(nl["vars_tise"])
+    inp = capi.make_input(**kw)
+    l0, m0, n0 = inp.l_ini, inp.m_ini, inp.n0_ini
+    lf, mf = final_channels(kind_pi, l0, m0)[-1]
+    prob = capi.Problem(inp, device)
+    if lf > prob.lmax:
+        prob.close()
+        raise ValueError("l_fin = l_ini + 1 = %d is beyond lmax = %d of the input (the reference reads an unallocated "
+                         "ci_fin in that case)" % (lf, prob.lmax))
+    E, info = prob.solve(0, prob.lmax + 1)
+    if any(info):
+        prob.close()
+        raise RuntimeError("ERROR DIAGONALIZING THE MATRIX! %s" % list(info))
+    n0f, n1f, _ = final_state_limits(E[lf], inp.emax_fin)
+    if n1f + 1 > prob.nfun:
+        prob.close()
+        raise ValueError("n1_fin = nfun: the density-of-states factor needs E_fin(n1_fin + 1)")
+    t3a = three_j(lf, 1, l0, -mf, mph, m0)
+    if kind_pi == 1:
+        t3b = three_j(lf, 1, l0, 0, 0, 0)
+        c1 = (-1.0) ** (lf + l0 + mf) * math.sqrt(float((2 * lf + 1) * (2 * l0 + 1))) * t3a * t3b
+        c0 = 1.0
+        a = [c1, 0.0, 0.0]                                         # A = c1 * int B r B
+    else:
+        c0 = math.sqrt(float(l0 + 1)) * t3a
+        c1, c2 = (float(l0 + 1), -1.0) if lf == l0 + 1 else ((float(l0), 1.0) if lf == l0 - 1 else (0.0, 0.0))
+        a = [0.0, c1, c2]                                          # A = c1 * int B B / r + c2 * int B B'
+    D = prob.dipole_elements(l0, n0, lf, n0f, n1f - n0f + 1, a)
+    Ef = E[lf]
+    T = np.array([math.sqrt(2.0 / (Ef[ni] - Ef[ni - 2])) * c0 * D[ni - n0f] for ni in range(n0f, n1f + 1)])
+    out = ["LIMITS FOR FINAL STATE (l=%2d) : %4d%4d" % (lf, n0f, n1f),                 # '(/,A26,I2,A3,X,2I4)'
+           "Calculating Transition Amplitudes",
+           "Initial State:%3d%3d%3d" % (n0 + l0, l0, m0)]                              # '(A14,3I3)'
+    prob.close()
+    return dict(E=E, l_fin=lf, m_fin=mf, n0_fin=n0f, n1_fin=n1f, T_fi=T, stdout="\n".join(out))

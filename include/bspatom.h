@@ -92,6 +92,16 @@ int bspatom_eigvec(bspatom_problem *p, int l, int n0, double *c);
  * Z[j*nfun + i] = component i of eigenvector n0+j.  Requires a previous bspatom_solve covering l. */
 int bspatom_eigvecs(bspatom_problem *p, int l, int n0, int count, double *Z);
 
+/* Dipole matrix elements between eigenvectors of the last solved batch: the DGEMV + DDOT of TRANS_AMP for the
+ * plane-wave branches KIND_PI = 1, 2 (reference PhotoIon.f90:95-107):
+ *   D[i] = c(l_fin, n0_fin + i)^T (a[0] R_r + a[1] R_{1/r} + a[2] R_{d/dr}) c(l_ini, n0_ini),  i = 0 .. count-1,
+ * with R_r = int B_i r B_j, R_{1/r} = int B_i B_j / r, R_{d/dr} = int B_i B_j' (the rij of MATRIX_SVT,
+ * matrices.f90:141-144,159-163) and S-normalised eigenvectors whose signs are this library's (first significant
+ * coefficient positive).  The reference's T_fi(n) = An c0 D: the angular factors c0, a[] (THREE_J) and the density of
+ * states An are host arithmetic (bspatom_amd/host.py::trans_amp).  n0_* are 1-based. */
+int bspatom_dipole_elements(bspatom_problem *p, int l_ini, int n0_ini, int l_fin, int n0_fin, int count,
+                            const double a[3], double *D);
+
 /* WRITE_WF (Bsp_Atom.f90:118-146): u(r_i) = sum_j c_j B_j(r_i), r_i = ra + i*(rb-ra)/npts,
  * i = 0..npts.  Returns BSPATOM_ERR_BSPLVB where the reference STOPs. r[npts+1], u[npts+1]. */
 int bspatom_write_wf(bspatom_problem *p, const double *c, int npts, double *r, double *u);

@@ -181,3 +181,82 @@ def solve_all(c, vectors_for=None):
         if want_v:
             vec = v[:, c.n0_ini - 1].copy()
     return E, vec, (rt, aind, xg, wg)
+
+
+# ---- transition amplitudes of the one-photon branches (KIND_PI = 1, 2) -------------------------------
+def three_j(j1, j2, j3, m1, m2, m3):
+    """Wigner 3j symbol for integer arguments by the Racah sum over log-factorials, the way the reference's THREE_J
+    does it (Funs_WignerSymbols.for:1-62): table FAC(i) = log((i-1)!) built by successive additions, the common
+    smallest exponent GROS taken out of the alternating sum, zero unless m1+m2+m3 = 0 and the z range is not empty."""
+    import math
+    nmax = 140
+    fac = [0.0] * (nmax + 1)                       # fac[i] = FAC(i), 1-based
+    for i in range(2, nmax + 1):
+        fac[i] = fac[i - 1] + math.log(float(i - 1))
+    l4 = j1 + j2 + j3 + 2
+    if l4 > nmax:
+        raise ValueError("THREE_J: arguments beyond the factorial table")
+    if m1 + m2 + m3 != 0:
+        return 0.0
+    izmax = min(j1 + j2 - j3, j1 - m1, j2 + m2) + 1
+    izmin = max(0, j2 - j3 - m1, j1 + m2 - j3) + 1
+    if izmax - izmin < 0:
+        return 0.0
+    l1 = j1 + j2 - j3 + 1; l2 = j3 + j1 - j2 + 1; l3 = j3 + j2 - j1 + 1
+    l5 = j1 + m1 + 1; l6 = j1 - m1 + 1; l7 = j2 + m2 + 1; l8 = j2 - m2 + 1; l9 = j3 + m3 + 1; l10 = j3 - m3 + 1
+    abra = 0.5 * (fac[l1] + fac[l2] + fac[l3] - fac[l4] + fac[l5] + fac[l6] + fac[l7] + fac[l8] + fac[l9] + fac[l10])
+    k1 = j3 - j2 + m1 + 1; k2 = j3 - j1 - m2 + 1
+    gros = 250.0
+    ac = {}
+    for ii in range(izmin, izmax + 1):
+        i = ii - 1
+        ac[ii] = fac[i + 1] + fac[l1 - i] + fac[l6 - i] + fac[l7 - i] + fac[k1 + i] + fac[k2 + i]
+        if ac[ii] < gros:
+            gros = ac[ii]
+    accu = 0.0
+    sig = (-1.0) ** izmin
+    for ii in range(izmin, izmax + 1):
+        sig = -sig
+        accu += sig * math.exp(-(ac[ii] - gros))
+    return (-1.0) ** (j1 - j2 - m3) * math.exp(abra - gros) * accu
+
+
+def final_state_limits(E_fin, emax_fin):
+    """n0_fin, n1_fin (1-based) as SOLVE_SYSTEM sets them for KIND_PI = 1, 2 at l = l_fin (matrices.f90:272-283):
+    last index with E < 0, plus one, capped at nfun-1; last index with E <= Emax_fin (Emax_fin = -1 means En(nfun))."""
+    n = len(E_fin)
+    if emax_fin == -1.0:
+        emax_fin = float(E_fin[-1])
+    n0 = -1; n1 = -1
+    for i in range(1, n + 1):
+        if E_fin[i - 1] < 0.0:
+            n0 = i
+        if E_fin[i - 1] <= emax_fin:
+            n1 = i
+    n0 = min(n0 + 1, n - 1)
+    return n0, n1, emax_fin
+
+
+def trans_amp(kind_pi, l0, m0, lf, mf, mph, R1, R2, ci_ini, ci_fin, E_fin, n0_fin, n1_fin):
+    """T_fi(ni), ni = n0_fin..n1_fin, of TRANS_AMP for the plane-wave branches (PhotoIon.f90:50-107).  R1, R2: dense
+    rij(:,:,1), rij(:,:,2) as MATRIX_SVT leaves them for this KIND_PI; ci_fin[:, ni - n0_fin]."""
+    t3a = three_j(lf, 1, l0, -mf, mph, m0)
+    if kind_pi == 1:
+        t3b = three_j(lf, 1, l0, 0, 0, 0)
+        c1 = (-1.0) ** (lf + l0 + mf) * np.sqrt(float((2 * lf + 1) * (2 * l0 + 1))) * t3a * t3b
+        c0 = 1.0
+        A = c1 * R1
+    else:
+        c0 = np.sqrt(float(l0 + 1)) * t3a
+        c1 = 0.0; c2 = 0.0
+        if lf == l0 + 1:
+            c1 = float(l0 + 1); c2 = -1.0
+        elif lf == l0 - 1:
+            c1 = float(l0); c2 = 1.0
+        A = c1 * R1 + c2 * R2
+    v = A @ ci_ini
+    T = np.zeros(n1_fin - n0_fin + 1)
+    for ni in range(n0_fin, n1_fin + 1):
+        An = np.sqrt(2.0 / (E_fin[ni] - E_fin[ni - 2]))          # E_fin(ni+1) - E_fin(ni-1), 1-based
+        T[ni - n0_fin] = An * c0 * float(ci_fin[:, ni - n0_fin] @ v)
+    return T

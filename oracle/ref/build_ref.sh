@@ -7,8 +7,9 @@
 #                               Enl.dat, wf_n0.dat), `INQUIRE(DIRECTORY=` (an ifort-only
 #                               extension, Bsp_Atom.f90:59) spelled `INQUIRE(FILE=` in a
 #                               temporary stream so that flang accepts it;
-#   oracle/_ref/ref_dump.x      ref_dump_driver.f90 + the same reference objects; also
-#                               writes ref_dump.bin (module state) for the golden fixtures.
+#   oracle/_ref/ref_dump.x      ref_dump_driver.f90 + the same reference objects (PhotoIon.f90 with one
+#                               diagnostic WRITE shortened, see below); also writes ref_dump.bin
+#                               (module state) for the golden fixtures.
 # LAPACK/BLAS: scipy's bundled OpenBLAS (LAPACK 3.12.0) through lapack_forward.c, since the
 # reference's `-mkl` is not in this image.  No reference source is copied into the repo:
 # the two filtered translation units live in a mktemp dir that is removed on exit.
@@ -37,6 +38,11 @@ sed "s/INQUIRE( DIRECTORY='CSs'/INQUIRE( FILE='CSs\/.'/" "$REF/src/Bsp_Atom.f90"
 # WRITE_WF / END_PROG only (everything after the program unit), for the dump driver
 sed -n '/^ *SUBROUTINE WRITE_WF/,$p' "$REF/src/Bsp_Atom.f90" > "$TMP/subs_unit.f90"
 "$FC" $FFLAGS -c "$TMP/subs_unit.f90" -o Bsp_Atom_subs.o
+# TRANS_AMP prints Enl(1,lf), Enl(n1_max,lf) (PhotoIon.f90:47), an array SOLVE_SYSTEM allocates for KIND_PI >= 3 only:
+# with flang the KIND_PI = 1, 2 run dies in that WRITE.  For the dump driver only, the two items are dropped from the
+# WRITE in a temporary stream (a diagnostic line; nothing computed changes), so that T_fi can be pinned
+sed "s/'Energy limits Final State:', Enl(1,lf), Enl(n1_max,lf)/'Energy limits Final State:'/" "$REF/src/PhotoIon.f90" > "$TMP/photoion_unit.f90"
+"$FC" $FFLAGS -c "$TMP/photoion_unit.f90" -o PhotoIon_dump.o
 "$FC" $FFLAGS -c "$HERE/ref_dump_driver.f90" -o ref_dump_driver.o
 gcc -O2 -c "$HERE/lapack_forward.c" -o lapack_forward.o
 COMMON="Modules.o ReadInputs.o matrices.o PhotoIon.o WriteWF.o grid.o CubicSpline.o bsplvb.o interv.o \
@@ -44,6 +50,6 @@ COMMON="Modules.o ReadInputs.o matrices.o PhotoIon.o WriteWF.o grid.o CubicSplin
  Funs_SphHarms.o Funs_Bessel.o Funs_WignerSymbols.o lapack_forward.o"
 LINK="$OPENBLAS -Wl,-rpath,$SCIPY_LIBS -lm"
 "$FC" -o "$OUT/Bsp_Atom_ref.x" Bsp_Atom.o $COMMON $LINK
-"$FC" -o "$OUT/ref_dump.x" ref_dump_driver.o Bsp_Atom_subs.o $COMMON $LINK
+"$FC" -o "$OUT/ref_dump.x" ref_dump_driver.o Bsp_Atom_subs.o ${COMMON/PhotoIon.o/PhotoIon_dump.o} $LINK
 rm -f *.mod
 echo "build_ref: built $OUT/Bsp_Atom_ref.x and $OUT/ref_dump.x (LAPACK: $OPENBLAS)"

@@ -34,9 +34,21 @@
       END IF
       CALL SOLVE_SYSTEM
       CALL SYSTEM_CLOCK(c2)
-!     (Continuing into TRANS_AMP / CROSS_SECTIONS for KIND_PI = 1, 2, as PROGRAM BSP_ATOM_PI does, is not
-!     possible with this build: TRANS_AMP prints Enl(1,lf), PhotoIon.f90:45, which SOLVE_SYSTEM allocates for
-!     KIND_PI >= 3 only -- the compiled reference segfaults there, so no amplitude fixtures exist.)
+!     KIND_PI = 1, 2: PROGRAM BSP_ATOM_PI continues into TRANS_AMP (Bsp_Atom.f90:77-80).  The unmodified routine
+!     dies in a diagnostic WRITE of an unallocated array (see build_ref.sh); with that line shortened it runs, and
+!     the amplitudes T_fi(n0_fin:n1_fin, l_fin) it leaves in the module are dumped for SURVEY 8(f).2.
+!     (CROSS_SECTIONS cannot follow: it COMPUTES with the unallocated Enl(n0,l0), PhotoIon.f90:302.)
+      IF( KIND_PI == 1 .OR. KIND_PI == 2 ) THEN
+        CALL TRANS_AMP
+        OPEN(UNIT=94, FILE='ref_tfi.bin', ACCESS='STREAM', FORM='UNFORMATTED', ACTION='WRITE')
+        WRITE(94) nfun, KIND_PI, n0_ini, lmf(0,1), lmf(0,2), lmf(nlm,1), lmf(nlm,2), mph, n0_fin, n1_fin
+        WRITE(94) Emax_fin
+        WRITE(94) E_ini(1:nfun), E_fin(1:nfun)
+        WRITE(94) ci_ini(1:nfun)
+        WRITE(94) ci_fin(1:nfun,n0_fin:n1_fin)
+        WRITE(94) T_fi(n0_fin:n1_fin,lmf(nlm,1))
+        CLOSE(94)
+      END IF
 !     KIND_PI >= 3: the state-selection bookkeeping SOLVE_SYSTEM leaves in the module (matrices.f90:290-358):
 !     n01(l,1:3), n1_max, Emax_fin as modified, the spectra Enl and the density-of-states factors rEki, for
 !     SURVEY 8(f).1 (the eigenvectors themselves are read from the Eigenvec_All.dat the same run wrote)

@@ -17,6 +17,7 @@ usage: python tests/golden/make_golden.py [case ...]      (default: all small ca
        python tests/golden/make_golden.py --big            (adds the n=2048/4096 spectra)
        python tests/golden/make_golden.py --dipole         (KIND_PI = 1, 2 dipole matrices rij)
        python tests/golden/make_golden.py --pi3            (KIND_PI >= 3: state limits, rEki, Eigenvec_All.dat)
+       python tests/golden/make_golden.py --amp            (KIND_PI = 1, 2: transition amplitudes T_fi of TRANS_AMP)
 """
 import json, os, subprocess, sys, tempfile, time
 import numpy as np
@@ -163,6 +164,50 @@ def run_pi3(name, text):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print("%-12s nfun=%3d lmax=%d KIND_PI=%d n1_max=%d n01=%s" % (name, nfun, lmax, kind_pi, n1_max, n01.tolist()), flush=True)
 
+# transition amplitudes T_fi of TRANS_AMP for KIND_PI = 1, 2 (PhotoIon.f90:50-107).  l_fin must be l_ini + 1
+# in the input (SEL_LM replaces it by that anyway, grid.f90:143, but lmax is derived from the input value before).
+def nml_amp(bsp, tise, kind_pi):
+    return "&VARS_BSP %s &end\n&VARS_TISE %s &end\n&VARS_FIELD KIND_PI=%d Eph=0.5D0 I0=1.0D14 &end\n" % (bsp, tise, kind_pi)
+
+AMP = {
+    "ta_len_s": nml_amp(_B64, "n0_ini=1 l_ini=0 l_fin=1 Emax_fin=1.0D0 Zatom=1.0D0", 1),       # 1s -> p, length gauge
+    "ta_vel_s": nml_amp(_B64, "n0_ini=1 l_ini=0 l_fin=1 Emax_fin=1.0D0 Zatom=1.0D0", 2),       # velocity gauge
+    "ta_len_p": nml_amp(_B64, "n0_ini=1 l_ini=1 l_fin=2 Emax_fin=0.6D0 Zatom=1.0D0", 1),       # 2p -> d
+    "ta_vel_p": nml_amp("KIND_GRID=1 ra=0.0D0 rb=120.0D0 k=8 nfun=80", "n0_ini=2 l_ini=1 l_fin=2 Emax_fin=0.8D0 Zatom=2.0D0", 2),
+}
+
+def run_amp(name, text):
+    inp = os.path.join(HERE, "inputs", name + ".inp")
+    with open(inp, "w") as f:
+        f.write("! golden-fixture input '%s' (generated by make_golden.py)\n" % name)
+        f.write(text)
+    with tempfile.TemporaryDirectory(prefix="bspgold.") as tmp:
+        with open(inp) as fin:
+            p = subprocess.run([REFX], stdin=fin, cwd=tmp, capture_output=True, text=True)
+        if p.returncode != 0:
+            raise RuntimeError("reference failed on %s:\n%s\n%s" % (name, p.stdout[-2000:], p.stderr[-2000:]))
+        raw = open(os.path.join(tmp, "ref_tfi.bin"), "rb").read()
+        h = [int(v) for v in np.frombuffer(raw[:40], dtype=np.int32)]
+        nfun, kind_pi, n0_ini, l0, m0, lf, mf, mph, n0_fin, n1_fin = h
+        off = 40
+        def take(cnt):
+            nonlocal off
+            a = np.frombuffer(raw[off: off + 8 * cnt], dtype=np.float64).copy(); off += 8 * cnt
+            return a
+        emax = take(1); E_ini = take(nfun); E_fin = take(nfun); ci_ini = take(nfun)
+        nf = n1_fin - n0_fin + 1
+        ci_fin = take(nfun * nf).reshape(nf, nfun).T.copy()           # (nfun, nf)
+        T = take(nf)
+        assert off == len(raw)
+        rr = open(os.path.join(tmp, "ref_rij.bin"), "rb").read()
+        R = np.frombuffer(rr[8:], dtype=np.float64).reshape(2, nfun, nfun)
+        sel = [l for l in p.stdout.split("\n") if ("LIMITS FOR FINAL" in l or "Initial State" in l or "Transition Amplitudes" in l)]
+        out = dict(head=np.array(h), emax_fin=emax, E_ini=E_ini, E_fin=E_fin, ci_ini=ci_ini, ci_fin=ci_fin, T_fi=T,
+                   r1=R[0].T.copy(), r2=R[1].T.copy(), lines=np.array("\n".join(sel)), namelist=np.array(open(inp).read()))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("%-10s KIND_PI=%d (n0,l0,m0)=(%d,%d,%d) -> (lf,mf)=(%d,%d) states %d..%d  max|T| %.6g" % (
+        name, kind_pi, n0_ini, l0, m0, lf, mf, n0_fin, n1_fin, np.max(np.abs(T))), flush=True)
+
 def upper_band(M, k):
     n = M.shape[0]
     B = np.zeros((k, n))
@@ -244,6 +289,11 @@ def main():
         args.remove("--dipole")
         for name in (args or list(DIPOLE)):
             run_dipole(name, *DIPOLE[name])
+        return
+    if "--amp" in args:
+        args.remove("--amp")
+        for name in (args or list(AMP)):
+            run_amp(name, AMP[name])
         return
     if "--pi3" in args:
         args.remove("--pi3")

@@ -382,3 +382,30 @@ def test_fortran_host_kind_pi3(tmp_path, name):
             sc = np.max(np.abs(R[l, ni]))
             d = min(np.max(np.abs(C[l, ni] - R[l, ni])), np.max(np.abs(C[l, ni] + R[l, ni]))) / sc
             assert d <= 2e-8, (l, ni, d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ta_len_s", "ta_vel_s", "ta_len_p", "ta_vel_p"])
+def test_transition_amplitudes_vs_reference(name):
+    """KIND_PI = 1 (length) and 2 (velocity) up to the end of TRANS_AMP (PhotoIon.f90:1-107) against the compiled
+    reference (one diagnostic WRITE shortened, oracle/ref/build_ref.sh): the final-state window exactly; T_fi(n) for
+    every final state INCLUDING its sign, after the reference's eigenvector signs (LAPACK's, arbitrary) are mapped to
+    this library's convention (first coefficient above 1e-8 positive) -- T is bilinear in the two vectors.  Tolerance:
+    1e-10 of max|T| on linear grids (measured 1e-13 .. 8e-13); 3e-7 on the grid with an exponential part, where two
+    LAPACK runs already differ by 2e-8 .. 3e-7 in the eigenvalues next to zero and those enter through the
+    density-of-states factor sqrt(2 / (E(n+1) - E(n-1))) (measured 1.7e-8)."""
+    from bspatom_amd import host
+    g = load_golden(name)
+    nfun, kp, n0i, l0, m0, lf, mf, mph, n0f, n1f = (int(v) for v in g["head"])
+    r = host.trans_amp(str(g["namelist"]))
+    assert (r["l_fin"], r["m_fin"], r["n0_fin"], r["n1_fin"]) == (lf, mf, n0f, n1f)
+    def conv_sign(c):                        # eigvec.hip: first coefficient above 1e-8 of the largest one is positive
+        big = np.where(np.abs(c) > 1e-8 * np.max(np.abs(c)))[0]
+        return 1.0 if (len(big) == 0 or c[big[0]] > 0) else -1.0
+    si = conv_sign(g["ci_ini"])
+    Tref = np.array([g["T_fi"][i] * si * conv_sign(g["ci_fin"][:, i]) for i in range(n1f - n0f + 1)])
+    err = np.max(np.abs(r["T_fi"] - Tref)) / np.max(np.abs(Tref))
+    note("trans_amp %s max|T| %.4g err %.2e" % (name, np.max(np.abs(Tref)), err))
+    assert err <= (3e-7 if "KIND_GRID=1" in str(g["namelist"]) else 1e-10), err
+    for line in r["stdout"].split("\n"):
+        assert line in [x.strip() for x in str(g["lines"]).split("\n")], line

@@ -149,3 +149,34 @@ def test_oracle_dipole_bands_bit_exact(name):
         assert np.array_equal(RB[0], g["r1f"])
     else:
         assert np.array_equal(RB[1], g["r1f"]) and np.array_equal(RB[2], g["r2f"])
+
+
+AMP_CASES = ["ta_len_s", "ta_vel_s", "ta_len_p", "ta_vel_p"]
+
+
+@pytest.mark.parametrize("name", AMP_CASES)
+def test_oracle_trans_amp_vs_reference(name):
+    """TRANS_AMP for KIND_PI = 1, 2 (PhotoIon.f90:50-107) restated: on the reference's own rij, eigenvectors and
+    spectrum the amplitudes T_fi(n0_fin:n1_fin) must come out to rounding (DGEMV / DDOT summation order is the BLAS
+    library's: 1e-13 of max|T|), the final-state window (matrices.f90:272-283) exactly."""
+    import oracle as orc
+    g = load_golden(name)
+    nfun, kp, n0i, l0, m0, lf, mf, mph, n0f, n1f = (int(v) for v in g["head"])
+    a, b, _ = orc.final_state_limits(g["E_fin"], float(g["emax_fin"][0]))
+    assert (a, b) == (n0f, n1f)
+    T = orc.trans_amp(kp, l0, m0, lf, mf, mph, g["r1"], g["r2"], g["ci_ini"], g["ci_fin"], g["E_fin"], n0f, n1f)
+    assert np.max(np.abs(T - g["T_fi"])) <= 1e-13 * np.max(np.abs(g["T_fi"]))
+
+
+def test_three_j_known_values():
+    """THREE_J restatement against closed forms: (l 1 l+1; 0 0 0)^2 = (l+1)/((2l+1)(2l+3)), (1 1 0; 0 0 0) = -1/sqrt 3,
+    selection rules, and the orthogonality sum over m."""
+    import oracle as orc
+    assert abs(orc.three_j(1, 1, 0, 0, 0, 0) + 1.0 / np.sqrt(3.0)) < 1e-15
+    for l in range(0, 8):
+        v = orc.three_j(l + 1, 1, l, 0, 0, 0)
+        assert abs(v * v - (l + 1.0) / ((2 * l + 1.0) * (2 * l + 3.0))) < 1e-14
+    assert orc.three_j(2, 1, 0, 0, 0, 0) == 0.0 and orc.three_j(1, 1, 1, 0, 0, 0) == 0.0 and orc.three_j(1, 1, 1, 1, 0, 0) == 0.0
+    for j3 in (1, 2, 3):
+        s = sum(orc.three_j(2, 1, j3, m1, m2, -m1 - m2) ** 2 for m1 in range(-2, 3) for m2 in (-1, 0, 1) if abs(m1 + m2) <= j3)
+        assert abs(s - 1.0) < 1e-13
