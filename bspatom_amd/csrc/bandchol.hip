@@ -90,13 +90,13 @@ __global__ __launch_bounds__(64) void std_form_kernel(int n, int npad, int k,
     double cur[64], nxt[64];
     if (PASS == 2) {
 #pragma unroll
-        for (int jj = 0; jj < 64; ++jj) cur[jj] = Y[(size_t)(jbeg + jj) * ld + r];
+        for (int jj = 0; jj < 64; ++jj) cur[jj] = __builtin_nontemporal_load(&Y[(size_t)(jbeg + jj) * ld + r]);
     }
     for (int j0 = jbeg; j0 < jend; j0 += 64) {
         if (PASS == 2) {
             const bool more = (j0 + 64 < jend);                // wave-uniform; clamped address, no branch around loads
 #pragma unroll
-            for (int jj = 0; jj < 64; ++jj) nxt[jj] = Y[(size_t)(more ? (j0 + 64 + jj) : jbeg) * ld + r];
+            for (int jj = 0; jj < 64; ++jj) nxt[jj] = __builtin_nontemporal_load(&Y[(size_t)(more ? (j0 + 64 + jj) : jbeg) * ld + r]);
         }
         __syncthreads();
         for (int idx = lane; idx < 64 * (B + 1); idx += 64) {
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) void std_form_kernel(int n, int npad, int k,
             v[jj] = acc * Lc[jj][0];
             tile[lane][jj] = v[jj];
             if (PASS == 2) {
-                if (j <= r) O[(size_t)j * ld + r] = v[jj];
+                if (j <= r) __builtin_nontemporal_store(v[jj], &O[(size_t)j * ld + r]);
             }
         }
 #pragma unroll
@@ -140,10 +140,10 @@ __global__ __launch_bounds__(64) void std_form_kernel(int n, int npad, int k,
         __syncthreads();
         // transposed store: element (r0+rr, j0+lane) of the pass result goes to (r0+rr)*ld + j0+lane
         if (PASS == 1) {
-            for (int rr = 0; rr < 64; ++rr) O[(size_t)(r0 + rr) * ld + j0 + lane] = tile[rr][lane];
+            for (int rr = 0; rr < 64; ++rr) __builtin_nontemporal_store(tile[rr][lane], &O[(size_t)(r0 + rr) * ld + j0 + lane]);
         } else {
             for (int rr = 0; rr < 64; ++rr)
-                if (j0 + lane < r0 + rr) O[(size_t)(r0 + rr) * ld + j0 + lane] = tile[rr][lane];
+                if (j0 + lane < r0 + rr) __builtin_nontemporal_store(tile[rr][lane], &O[(size_t)(r0 + rr) * ld + j0 + lane]);
         }
     }
 }

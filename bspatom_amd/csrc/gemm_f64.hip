@@ -386,6 +386,17 @@ __device__ __forceinline__ void tile_offsets(unsigned (&off)[BK * BX / 512], lon
     }
 }
 
+#ifndef G2_NT
+#define G2_NT 1
+#endif
+// streaming (non-temporal) 16-byte load: the A22 tiles of symm pass through once per use and should not push W and
+// the panels out of the L2
+__device__ __forceinline__ double2 g2_ldnt(const char *p)
+{
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const d2_t v = G2_NT ? __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(p)) : *reinterpret_cast<const d2_t *>(p);
+    return make_double2(v.x, v.y);
+}
 // kernel view: C'(i', j') with j' memory-contiguous (sCn == 1 required).
 template <int BM, int BN, int ALAY, int BLAY, int MODE, int DIAGG = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm2_kernel(GemmDesc g)
@@ -465,10 +476,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {                                                                                                        \
         if (MODE == 2 && (k0_) >= ksw) {                                                                     \
             const char *kb_ = reinterpret_cast<const char *>(B) + (long)(k0_) * 8;                           \
-            _Pragma("unroll") for (int it = 0; it < NRB; ++it) rb[it] = *reinterpret_cast<const double2 *>(kb_ + offT[it]); \
+            _Pragma("unroll") for (int it = 0; it < NRB; ++it) rb[it] = g2_ldnt(kb_ + offT[it]);            \
         } else {                                                                                             \
             const char *kb_ = reinterpret_cast<const char *>(B) + (long)(k0_) * ksB;                         \
-            _Pragma("unroll") for (int it = 0; it < NRB; ++it) rb[it] = *reinterpret_cast<const double2 *>(kb_ + offB[it]); \
+            _Pragma("unroll") for (int it = 0; it < NRB; ++it) rb[it] = g2_ldnt(kb_ + offB[it]);            \
         }                                                                                                    \
     }
 #define G2_STORE_B(k0_, S_, rb)                                              \
@@ -503,7 +514,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int r = 0; r < 4; ++r) {
                 const double *pr = Cl + (long)(16 * i + 4 * r) * g.sCm;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j][r] = sc * pr[16 * j];
+                for (int j = 0; j < TN; ++j) acc[i][j][r] = sc * (G2_NT ? __builtin_nontemporal_load(&pr[16 * j]) : pr[16 * j]);
             }
     } else if (beta != 0.0) {
         const double sc = beta / alpha;
@@ -593,7 +604,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int r = 0; r < 4; ++r) {
                 double *pr = Cl + (long)(16 * i + 4 * r) * g.sCm;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) pr[16 * j] = alpha * acc[i][j][r];
+                for (int j = 0; j < TN; ++j) { if (G2_NT) __builtin_nontemporal_store(alpha * acc[i][j][r], &pr[16 * j]); else pr[16 * j] = alpha * acc[i][j][r]; }
             }
     } else {
 #pragma unroll
