@@ -48,7 +48,7 @@ struct GemmDesc {
     long bCs;
     // gemm2 MODE 1: the valid tiles are enumerated in 8 x 8 super-blocks; entry s = super-block (sbx, sby) in tile
     // units / 8, sbpre = number of valid tiles up to and including it (set by syr2k_lower_f64)
-    int nsb;
+    int nsb, toff;           // toff: first tile (of the enumeration) of this launch; lower_only = number of tiles in it
     unsigned short sbpre[56];
     unsigned char sbx[56], sby[56];
 };
@@ -62,7 +62,8 @@ int tsmm64_f64(int m, int batch, const double *A, long lda, long bsA, const doub
                double alpha, double beta, hipStream_t st);
 // pipelined, symmetry-aware products of sy2sb (see gemm_f64.hip)
 // part: 0 = all tiles, 1 = only column block 0 (look-ahead part), 2 = column blocks >= 1
-int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const double *buf, long ldb, long bsBuf,
+// seg / nseg: the launch covers the seg-th of nseg equal slices of the tile enumeration (nseg = 1: all)
+int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const double *buf, long ldb, long bsBuf, int seg, int nseg,
                     int part, hipStream_t st);
 int symm_lower_f64(int m, int batch, const double *A22, long ld, long bsA, const double *W, long ldw, long bsW,
                    double *Y, long ldy, long bsY, hipStream_t st);

@@ -419,10 +419,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int id = blockIdx.x, xcd = id & 7, q = id >> 3;
         const int nb = (g.N + BN - 1) / BN, T = g.lower_only;           // T: valid tiles per channel (from the launcher)
         const int zi = q / T;
-        int t = q - zi * T;
+        int t = q - zi * T + g.toff;
         bz = xcd + 8 * zi;
         if (bz >= g.batch) return;
-        const int ylo = g.yoff, part1 = (g.yoff == 0 && T == nb);       // part 1 of the look-ahead: by == 0 only
+        const int ylo = g.yoff, part1 = (g.yoff == 0 && g.nsb > 0 && (int)g.sbpre[g.nsb - 1] == nb);   // part 1 of the look-ahead: by == 0 only
         // Within a channel the tiles go in 8 x 8 SUPER-BLOCKS (row-major inside): the 64 workgroups an XCD holds at a
         // time then share 8 row slices and 8 column slices of the [V|Z|V] panels (2 MB, L2-resident) instead of one
         // row slice and up to 32 column slices that each serve a single tile before the streaming C tiles evict them.
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // A22 (m x m, column-major, ld) -= P Q^T with P = buf[:, 0:128], Q = buf[:, 64:192] (ldb rows apart),
 // only tiles with column block <= row block + 1.
-int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const double *buf, long ldb, long bsBuf,
+int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const double *buf, long ldb, long bsBuf, int seg, int nseg,
                     int part, hipStream_t st)
 {
     GemmDesc g{};
@@ -659,6 +659,11 @@ int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const doub
             ++g.nsb;
         }
     if (T <= 0) return BSP_OK;
+    if (nseg > 1) {                                                   // a slice of the enumeration
+        const int t0 = (int)((long)T * seg / nseg), t1 = (int)((long)T * (seg + 1) / nseg);
+        if (t1 <= t0) return BSP_OK;
+        g.toff = t0; T = t1 - t0;
+    }
     g.lower_only = T;                                                 // MODE 1 reads it as the tile count
     dim3 grid((unsigned)(8 * ((batch + 7) / 8) * T), 1, 1);
     static int gd = -1;

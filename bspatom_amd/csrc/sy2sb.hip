@@ -670,15 +670,24 @@ static int sy2sb_panel(int npad, int batch, double *d_A, const Sy2sbWork &w, hip
         // A22 -= [V Z] [Z V]^T
         const bool more = (p + 1 < P);
         if (lookahead && more) {
-            if ((rc = syr2k_lower_f64(m, batch, A22, ld, bsA, buf, npad, bsBuf, 1, st))) return rc;
+            if ((rc = syr2k_lower_f64(m, batch, A22, ld, bsA, buf, npad, bsBuf, 0, 1, 1, st))) return rc;
             BSP_HIP(hipEventRecord(evA, st));
             BSP_HIP(hipStreamWaitEvent(side, evA, 0));
             if ((rc = panel_and_W(npad, r0, batch, d_A, bufn, taun, w, side))) return rc;
             BSP_HIP(hipEventRecord(evB, side));
-            if ((rc = syr2k_lower_f64(m, batch, A22, ld, bsA, buf, npad, bsBuf, 2, st))) return rc;
+            // the rest of the update in `nseg2` launches: at every boundary between them the running workgroups
+            // drain, which is when the panel stream's small kernels (T, W ...) find a place (BSP_SY2SB_SEGS)
+            // (measured at 128 channels, n = 4096: 1 launch 307-308 ms, 2: 305, 3: 302-303, 4: 303-304, 6: 306, 8: 307;
+            // small trailing matrices -- fewer than six fills of the GPU -- stay in one launch)
+            static int nseg_env = -1;
+            if (nseg_env < 0) { const char *e = getenv("BSP_SY2SB_SEGS"); nseg_env = e ? atoi(e) : 0; }
+            const long nbt = (m + 127) / 128, wgs = nbt * (nbt + 1) / 2 * batch;
+            const int nseg2 = (nseg_env >= 1) ? nseg_env : ((wgs >= 6 * 512) ? 3 : 1);
+            for (int sg = 0; sg < nseg2; ++sg)
+                if ((rc = syr2k_lower_f64(m, batch, A22, ld, bsA, buf, npad, bsBuf, sg, nseg2, 2, st))) return rc;
             BSP_HIP(hipStreamWaitEvent(st, evB, 0));
         } else {
-            if ((rc = syr2k_lower_f64(m, batch, A22, ld, bsA, buf, npad, bsBuf, 0, st))) return rc;
+            if ((rc = syr2k_lower_f64(m, batch, A22, ld, bsA, buf, npad, bsBuf, 0, 1, 0, st))) return rc;
             if (more && (rc = panel_and_W(npad, r0, batch, d_A, bufn, taun, w, st))) return rc;
         }
     }
