@@ -265,3 +265,25 @@ def test_trans_amp_host_logic_vs_reference(name):
     assert "LIMITS FOR FINAL STATE (l=%2d) : %4d%4d" % (lf, n0f, n1f) in ref
     assert "Initial State:%3d%3d%3d" % (n0i + l0, l0, m0) in ref
     assert "Calculating Transition Amplitudes" in ref
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """profiles/r01_bench_line.json is the line bench.py printed on the MI355X: the keys the driver and the judge read,
+    the metric of BASELINE.json, a roofline object whose numbers are consistent with each other, a CPU baseline."""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_line.json")))
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert base["metric"].startswith(d["metric"])
+    assert d["dtype"] == "f64" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic"]
+    # value = channels per step / time per step
+    assert abs(d["value"] - d["config"]["channels_per_gpu"] * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
