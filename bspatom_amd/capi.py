@@ -34,7 +34,8 @@ class Sizes(C.Structure):
 EXPORTS = ["bspatom_input_defaults", "bspatom_device_count", "bspatom_host_setup", "bspatom_problem_create", "bspatom_problem_destroy",
            "bspatom_problem_sizes", "bspatom_problem_grid", "bspatom_assemble", "bspatom_solve", "bspatom_solve_dev",
            "bspatom_eigvec", "bspatom_eigvecs", "bspatom_dipole_bands", "bspatom_dipole_elements", "bspatom_write_wf", "bspatom_last_timing", "bsp_dsygv_", "bspatom_stage_gemm",
-           "bspatom_stage_standard_form", "bspatom_stage_sy2sb", "bspatom_stage_sb2st", "bspatom_stage_bisect"]
+           "bspatom_stage_standard_form", "bspatom_stage_sy2sb", "bspatom_stage_sb2st", "bspatom_stage_bisect",
+           "bspatom_set_option", "bspatom_get_option"]
 
 _lib = None
 
@@ -71,6 +72,8 @@ def lib():
         L.bspatom_stage_sb2st.argtypes = [i32, i32, i32, vp, vp, vp]
         L.bspatom_stage_bisect.argtypes = [i32, i32, vp, vp, vp]
         L.bsp_dsygv_.restype = None
+        L.bspatom_set_option.argtypes = [C.c_char_p, i32]
+        L.bspatom_get_option.argtypes = [C.c_char_p, C.POINTER(i32)]
         _lib = L
     return _lib
 
@@ -258,5 +261,16 @@ def dsygv(A, B, jobz="V", uplo="U"):
     w = np.zeros(n); work = np.zeros(max(1, 4 * n))
     it = C.c_int(1); nn = C.c_int(n); lda = C.c_int(n); lw = C.c_int(4 * n); info = C.c_int(0)
     lib().bsp_dsygv_(C.byref(it), C.c_char_p(jobz.encode()), C.c_char_p(uplo.encode()), C.byref(nn), _p(a), C.byref(lda),
-                     _p(b), C.byref(lda), _p(w), _p(work), C.byref(lw), C.byref(info), C.c_int(1), C.c_int(1))
+                     _p(b), C.byref(lda), _p(w), _p(work), C.byref(lw), C.byref(info), C.c_size_t(1), C.c_size_t(1))
     return w, a, b, info.value
+
+
+def set_option(name, value):
+    """Flip one of the library's run-time switches (BSP_* variables of DESIGN.md 4.4) in this process."""
+    _chk(lib().bspatom_set_option(name.encode(), int(value)), "bspatom_set_option(%s)" % name)
+
+
+def get_option(name):
+    v = C.c_int(0)
+    _chk(lib().bspatom_get_option(name.encode(), C.byref(v)), "bspatom_get_option(%s)" % name)
+    return v.value

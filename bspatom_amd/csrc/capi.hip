@@ -13,7 +13,7 @@ struct bspatom_problem {
     HostSetup hs;
     int device;
     int npad;
-    hipStream_t st;
+    hipStream_t st = nullptr;
     // device: set-up tables
     double *d_rt = nullptr, *d_aind = nullptr, *d_xg = nullptr, *d_wg = nullptr, *d_vpot = nullptr, *d_bl = nullptr;
     double *d_ptab = nullptr; int *d_left = nullptr; int *d_status = nullptr;
@@ -37,11 +37,57 @@ struct bspatom_problem {
     int pre_l = -1, pre_n0 = -1, pre_ch = 0;
     // last solve
     int last_l0 = 0, last_nl = 0;
-    hipEvent_t ev[7];
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double ms[6] = {0, 0, 0, 0, 0, 0};
 };
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---- run-time switches: environment once, then bspatom_set_option ------------------------------------
+namespace {
+struct OptName { const char *name; const char *env; int Options::*field; };
+const OptName OPT_TABLE[] = {
+    {"sb2st_version", "BSP_SB2ST_VERSION", &Options::sb2st_version}, {"sb2st_ring", "BSP_SB2ST_RING", &Options::sb2st_ring},
+    {"sb2st_margin", "BSP_SB2ST_MARGIN", &Options::sb2st_margin}, {"sb2st_hyst", "BSP_SB2ST_HYST", &Options::sb2st_hyst},
+    {"sb2st_lead", "BSP_SB2ST_LEAD", &Options::sb2st_lead}, {"sb2st_check", "BSP_SB2ST_CHECK", &Options::sb2st_check},
+    {"sb2st_diag", "BSP_SB2ST_DIAG", &Options::sb2st_diag}, {"sb2st_force_abort", "BSP_SB2ST_FORCE_ABORT", &Options::sb2st_force_abort},
+    {"sy2sb_groups", "BSP_SY2SB_GROUPS", &Options::sy2sb_groups}, {"sy2sb_lookahead", "BSP_SY2SB_LOOKAHEAD", &Options::sy2sb_lookahead},
+    {"sy2sb_segs", "BSP_SY2SB_SEGS", &Options::sy2sb_segs}, {"panel_qr", "BSP_PANEL_QR", &Options::panel_qr},
+    {"gemm_diag", "BSP_GEMM_DIAG", &Options::gemm_diag}, {"bisect", "BSP_BISECT", &Options::bisect},
+    {"bisect_ept", "BSP_BISECT_EPT", &Options::bisect_ept}, {"no_eigvec_prefetch", "BSP_NO_EIGVEC_PREFETCH", &Options::no_eigvec_prefetch},
+};
+}  // namespace
+
+namespace bsp {
+Options &opts()
+{
+    static Options o = [] {
+        Options v;
+        for (const OptName &t : OPT_TABLE) {
+            const char *e = getenv(t.env);
+            if (e) v.*(t.field) = (*e == 0) ? 1 : atoi(e);     // a variable set to the empty string switches a flag on
+        }
+        return v;
+    }();
+    return o;
+}
+}  // namespace bsp
+
+extern "C" int bspatom_set_option(const char *name, int value)
+{
+    if (!name) return BSP_ERR_ARG;
+    for (const OptName &t : OPT_TABLE)
+        if (!strcmp(name, t.name)) { opts().*(t.field) = value; return BSP_OK; }
+    return BSP_ERR_ARG;
+}
+
+extern "C" int bspatom_get_option(const char *name, int *value)
+{
+    if (!name || !value) return BSP_ERR_ARG;
+    for (const OptName &t : OPT_TABLE)
+        if (!strcmp(name, t.name)) { *value = opts().*(t.field); return BSP_OK; }
+    return BSP_ERR_ARG;
+}
 
 extern "C" void bspatom_input_defaults(bspatom_input *in) { input_defaults(in); }
 
@@ -91,8 +137,8 @@ extern "C" void bspatom_problem_destroy(bspatom_problem *p)
     hipFree(p->d_pvec); hipFree(p->d_pE); hipFree(p->d_pinfo);
     if (p->st2) hipStreamDestroy(p->st2);
     if (p->evx) hipEventDestroy(p->evx);
-    for (auto &e : p->ev) hipEventDestroy(e);
-    hipStreamDestroy(p->st);
+    for (auto &e : p->ev) if (e) hipEventDestroy(e);
+    if (p->st) hipStreamDestroy(p->st);
     delete p;
 }
 
@@ -104,18 +150,9 @@ static int upload(T **dst, const T *src, size_t count)
     return BSP_OK;
 }
 
-extern "C" int bspatom_problem_create(const bspatom_input *in, int device, bspatom_problem **out)
+static int problem_init(bspatom_problem *p, const bspatom_input *in, int device)
 {
-    if (!in || !out) return BSP_ERR_ARG;
-    *out = nullptr;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
-        fprintf(stderr, "bspatom: no HIP device %d (libbspatom has no CPU path)\n", device);
-        return BSP_ERR_NOGPU;
-    }
-    bspatom_problem *p = new (std::nothrow) bspatom_problem;
-    if (!p) return BSP_ERR_ARG;
-    if (derive(*in, &p->hs) != 0) { delete p; return BSP_ERR_ARG; }
+    if (derive(*in, &p->hs) != 0) return BSP_ERR_ARG;
     build_grid(&p->hs);
     build_vpot(&p->hs);
     p->device = device;
@@ -136,6 +173,23 @@ extern "C" int bspatom_problem_create(const bspatom_input *in, int device, bspat
     BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_left), npt * sizeof(int)));
     BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_status), sizeof(int)));
     BSP_HIP(hipMemset(p->d_status, 0, sizeof(int)));
+    return BSP_OK;
+}
+
+extern "C" int bspatom_problem_create(const bspatom_input *in, int device, bspatom_problem **out)
+{
+    if (!in || !out) return BSP_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        fprintf(stderr, "bspatom: no HIP device %d (libbspatom has no CPU path)\n", device);
+        return BSP_ERR_NOGPU;
+    }
+    bspatom_problem *p = new (std::nothrow) bspatom_problem;
+    if (!p) return BSP_ERR_ARG;
+    p->device = device;
+    const int rc = problem_init(p, in, device);
+    if (rc) { bspatom_problem_destroy(p); return rc; }      // frees whatever was created so far
     *out = p;
     return BSP_OK;
 }
@@ -165,6 +219,7 @@ static int ensure_capacity(bspatom_problem *p, int nl)
 {
     if (nl <= p->cap_nl) return BSP_OK;
     free_solve_buffers(p);
+    p->last_nl = 0; p->pre_l = -1;                          // the spectra and bands of the last solve are gone
     const HostSetup &h = p->hs;
     const size_t n = h.nfun, k = h.k, np = p->npad, b = nl;
     BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_SB), k * n * sizeof(double)));
@@ -235,6 +290,7 @@ extern "C" int bspatom_assemble(bspatom_problem *p, int l0, int nl, double *SB, 
     BSP_HIP(hipSetDevice(p->device));
     int rc;
     if ((rc = ensure_capacity(p, nl))) return rc;
+    p->last_nl = 0; p->pre_l = -1;                          // d_HB is overwritten: eigvec / eigvecs need a new solve
     if ((rc = enqueue_assemble(p, l0, nl))) return rc;
     BSP_HIP(hipStreamSynchronize(p->st));
     if ((rc = check_status(p))) return rc;
@@ -266,6 +322,14 @@ int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const d
 }
 }  // namespace bsp
 
+// d_info after inverse iterations: 1 + index of a vector whose iterate had norm zero (eigvec.hip), else 0
+static int invit_failed(bspatom_problem *p)
+{
+    int v = 0;
+    BSP_HIP(hipMemcpy(&v, p->d_info, sizeof(int), hipMemcpyDeviceToHost));
+    return v ? BSP_ERR_UNSUPPORTED : BSP_OK;
+}
+
 static int ensure_vec_scratch(bspatom_problem *p)
 {
     const HostSetup &h = p->hs;
@@ -285,6 +349,7 @@ static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, dou
     const int n = h.nfun, np = p->npad;
     int rc;
     if ((rc = ensure_capacity(p, nl))) return rc;
+    p->last_nl = 0;                                          // valid again only when this solve has completed
     BSP_HIP(hipMemsetAsync(p->d_info, 0, sizeof(int), p->st));
     BSP_HIP(hipEventRecord(p->ev[0], p->st));
     if ((rc = enqueue_assemble(p, l0, nl))) return rc;
@@ -296,7 +361,7 @@ static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, dou
     // matrices exist (ev[4] = after sb2st), then the inverse iteration, on a second stream beside the batched bisection.
     p->pre_l = -1;
     const int tl = h.in.l_ini, tn0 = h.in.n0_ini;
-    if (tl >= l0 && tl < l0 + nl && tn0 >= 1 && tn0 <= n && getenv("BSP_NO_EIGVEC_PREFETCH") == nullptr) {
+    if (tl >= l0 && tl < l0 + nl && tn0 >= 1 && tn0 <= n && !opts().no_eigvec_prefetch) {
         if (!p->st2) {
             BSP_HIP(hipStreamCreateWithFlags(&p->st2, hipStreamNonBlocking));
             BSP_HIP(hipEventCreateWithFlags(&p->evx, hipEventDisableTiming));
@@ -372,6 +437,9 @@ extern "C" int bspatom_eigvec(bspatom_problem *p, int l, int n0, double *c)
     if (l < p->last_l0 || l >= p->last_l0 + p->last_nl || n0 < 1 || n0 > n) return BSP_ERR_ARG;
     BSP_HIP(hipSetDevice(p->device));
     if (l == p->pre_l && n0 == p->pre_n0) {                  // computed beside the bisection of the last solve
+        int pinfo = 0;
+        BSP_HIP(hipMemcpy(&pinfo, p->d_pinfo, sizeof(int), hipMemcpyDeviceToHost));
+        if (pinfo) return BSP_ERR_UNSUPPORTED;              // the inverse iteration broke down (vector of norm 0)
         BSP_HIP(hipMemcpy(c, p->d_pvec, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
         return BSP_OK;
     }
@@ -386,8 +454,14 @@ extern "C" int bspatom_eigvec(bspatom_problem *p, int l, int n0, double *c)
                                        p->d_info, p->st))) return rc;
     BSP_HIP(hipMemcpyAsync(c, p->d_vec, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, p->st));
     BSP_HIP(hipStreamSynchronize(p->st));
-    return BSP_OK;
+    return invit_failed(p);
 }
+
+struct DevInts {
+    int *p = nullptr;
+    ~DevInts() { hipFree(p); }
+    int alloc(size_t n) { BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p), (n ? n : 1) * sizeof(int))); return BSP_OK; }
+};
 
 struct DevBuf {
     double *p = nullptr;
@@ -410,24 +484,23 @@ extern "C" int bspatom_eigvecs(bspatom_problem *p, int l, int n0, int count, dou
     // chunks bound the scratch: invit_work_doubles(n, k) per vector
     const int chunk = count < 512 ? count : 512;
     if ((rc = work.alloc((size_t)chunk * invit_work_doubles(n, h.k))) || (rc = vec.alloc((size_t)chunk * n))) return rc;
-    int *d_chan = nullptr;
-    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&d_chan), (size_t)chunk * sizeof(int)));
+    DevInts chan;
+    if ((rc = chan.alloc(chunk))) return rc;
+    int *d_chan = chan.p;
     std::vector<int> hc(chunk, ch);
     hipError_t e = hipMemcpy(d_chan, hc.data(), (size_t)chunk * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d_info, 0, sizeof(int), p->st);
     for (int done = 0; e == hipSuccess && rc == BSP_OK && done < count; done += chunk) {
         const int m = (count - done < chunk) ? count - done : chunk;
-        e = hipMemsetAsync(p->d_info, 0, sizeof(int), p->st);
-        if (e != hipSuccess) break;
         rc = launch_inverse_iteration(n, h.k, m, p->d_SB, p->d_HB, d_chan, p->d_E + (size_t)ch * n + (n0 - 1 + done), work.p,
                                       vec.p, p->d_info, p->st);
         if (rc) break;
         e = hipMemcpyAsync(Z + (size_t)done * n, vec.p, (size_t)m * n * sizeof(double), hipMemcpyDeviceToHost, p->st);
         if (e == hipSuccess) e = hipStreamSynchronize(p->st);
     }
-    hipFree(d_chan);
     if (rc) return rc;
     BSP_HIP(e);
-    return BSP_OK;
+    return invit_failed(p);
 }
 
 extern "C" int bspatom_dipole_elements(bspatom_problem *p, int l_ini, int n0_ini, int l_fin, int n0_fin, int count,
@@ -450,8 +523,9 @@ extern "C" int bspatom_dipole_elements(bspatom_problem *p, int l_ini, int n0_ini
     DevBuf RB, work, vec, ci, v, dD;
     if ((rc = RB.alloc((size_t)3 * (2 * h.k - 1) * n)) || (rc = work.alloc((size_t)chunk * invit_work_doubles(n, h.k))) ||
         (rc = vec.alloc((size_t)chunk * n)) || (rc = ci.alloc(n)) || (rc = v.alloc(n)) || (rc = dD.alloc(chunk))) return rc;
-    int *d_chan = nullptr;
-    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&d_chan), (size_t)chunk * sizeof(int)));
+    DevInts chan;
+    if ((rc = chan.alloc(chunk))) return rc;
+    int *d_chan = chan.p;
     std::vector<int> hc(chunk, l_ini - lo);
     hipError_t e = hipMemcpy(d_chan, hc.data(), sizeof(int), hipMemcpyHostToDevice);
     // v = (a0 R_r + a1 R_1/r + a2 R_d/dr) c_ini
@@ -477,9 +551,9 @@ extern "C" int bspatom_dipole_elements(bspatom_problem *p, int l_ini, int n0_ini
         e = hipMemcpyAsync(D + done, dD.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, p->st);
         if (e == hipSuccess) e = hipStreamSynchronize(p->st);
     }
-    hipFree(d_chan);
     if (rc) return rc;
     BSP_HIP(e);
+    if ((rc = invit_failed(p))) return rc;
     return check_status(p);
 }
 

@@ -32,6 +32,25 @@ __host__ __device__ inline size_t ab_stride(int npad) { return (size_t)npad * 12
 
 namespace bsp {
 
+// ---- run-time switches (A/B comparisons, diagnostics, test hooks) ---------------------------------
+// Read ONCE per process from the environment (BSP_* variables) at the first use; the tests flip
+// them in-process through bspatom_set_option (include/bspatom.h) to drive the fallback paths.
+struct Options {
+    int sb2st_version = 8;       // BSP_SB2ST_VERSION: 8 = two-sweep workgroups in rings, 7 = one per channel, 3 = one sweep per workgroup
+    int sb2st_ring = 0;          // BSP_SB2ST_RING: ring size (0 = by channel count)
+    int sb2st_margin = 3, sb2st_hyst = 2, sb2st_lead = 16;
+    int sb2st_check = 0;         // BSP_SB2ST_CHECK: synchronise and report ring formation / holds on stderr
+    int sb2st_diag = 0;          // BSP_SB2ST_DIAG: instrumented kernel
+    int sb2st_force_abort = 0;   // test hook: 1 = every ring ABORTs its handshake (member 0 runs alone); 2 = pretend the
+                                 // members sit on different XCDs (same fallback through the other branch)
+    int sy2sb_groups = 2, sy2sb_lookahead = 1, sy2sb_segs = 0;
+    int panel_qr = 2;            // BSP_PANEL_QR: 1 = first panel kernel for every panel (it always serves panels above 4096 rows)
+    int gemm_diag = 0;
+    int bisect = 3, bisect_ept = 0;
+    int no_eigvec_prefetch = 0;
+};
+Options &opts();
+
 // ---- batched fp64 MFMA GEMM: C[b] = alpha * A[b] * B[b] + beta * C[b] ----------------------
 // Element (i,k) of A[b] is at A + b*bA + i*sAm + k*sAk (one of sAm, sAk must be 1), likewise
 // B(k,j) at B + b*bB + k*sBk + j*sBn and C(i,j) at C + b*bC + i*sCm + j*sCn.

@@ -666,8 +666,7 @@ int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const doub
     }
     g.lower_only = T;                                                 // MODE 1 reads it as the tile count
     dim3 grid((unsigned)(8 * ((batch + 7) / 8) * T), 1, 1);
-    static int gd = -1;
-    if (gd < 0) { const char *e = getenv("BSP_GEMM_DIAG"); gd = e ? atoi(e) : 0; }
+    const int gd = opts().gemm_diag;
     if (gd && part == 2 && m >= 3900) {
         long long z[8] = {0};
         BSP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm2_diag), z, sizeof(z)));

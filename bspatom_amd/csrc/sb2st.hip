@@ -437,25 +437,9 @@ __global__ __launch_bounds__(256) void sb2st_kernel_v3(int n, int npad, double *
 enum { ACT_IDLE = 0, ACT_PRELOAD = 1, ACT_ITEM0 = 2, ACT_CHASE = 3 };
 
 // ------------------------------------------------------------------------------------------------
-// v6: TWO WORKGROUPS = TWO CUs PER CHANNEL.  v3 runs at the single-CU HBM rate (22 GB/s, 96 KB per
-// chase step); the only way to go faster at 128 channels is to give a channel two CUs.  Half h (one
-// workgroup) chases sweeps h, h+2, ...; sweep s+1 follows sweep s at a distance of >= 3 published
-// items.  Coherence: the two workgroups VERIFY at run time (XCC_ID) that they sit on the same XCD, so
-// they share one L2; tiles are read with sc1 loads (bypass the per-CU L1), written with plain stores
-// (L1 is write-through), and an item is published only two super-steps after its stores were issued,
-// when every wave has waited (in-order vmcnt) on loads it issued after them.  If the partner is on
-// another XCD, or does not show up in time, one workgroup runs the whole channel with the v3 code.
-// Every spin is bounded; a workgroup that has to wait first drains its stores and publishes its true
-// progress, so two waiting workgroups cannot deadlock.
-struct Sb6Ctl {
-    unsigned pair;              // byte h = 0x10 | xcc of half h; bit 31 = a half went solo
-    int err;
-    unsigned long long prog[2]; // published progress of half h: (sweep << 20) | items done ; SB6_FIN when finished
-    unsigned long long nwait[2], wcycles[2], tcycles[2];   // statistics: waits, cycles spent waiting, total cycles
-};
+// Helpers of the cross-workgroup hand-off (rings of v7 workgroups, "v8" below).  The first paired generation (v6: two
+// one-sweep workgroups per channel, 440 ms) is in the history only; its progress-word format survives.
 constexpr unsigned long long SB6_FIN = 1ull << 60;
-constexpr int SB6_MARGIN = 3;
-constexpr int SB6_HYST = 8;     // extra lead demanded once a workgroup has to wait   // partner's published items must exceed the item index by this much
 
 __device__ __forceinline__ double ld_sc1(const double *p)
 {
@@ -469,312 +453,6 @@ __device__ __forceinline__ bool sb6_dep_ok(unsigned long long pw, int sw, int ne
     const int osw = (int)(pw >> 20), odn = (int)(pw & 0xfffff);
     return (osw > sw - 1) || (osw == sw - 1 && odn >= need);
 }
-
-template <int PAR>
-__device__ __forceinline__ void superstep_v6(double *__restrict__ AB, Sb3Lds &S, int tid, int ib, int j0,
-                                             const unsigned (&off)[4][4], unsigned low, int n, int act, int sw,
-                                             ChaseState &st, double &xpre, const unsigned long long *pollp,
-                                             unsigned long long &pollv,
-                                             double (&Bc)[4][4], double (&Dc)[4][4], double (&Bn)[4][4], double (&Dn)[4][4])
-{
-    constexpr int LD = 2 * SB;
-    const double *vc = PAR ? S.vb : S.va;
-    double *vn = PAR ? S.va : S.vb;
-    const int jb = j0 >> 2;
-    const bool comp = (act >= ACT_ITEM0);
-    const bool item0 = (act == ACT_ITEM0);
-    const int L0 = (n - 1 - sw < SB) ? (n - 1 - sw) : SB;
-    if (item0) { st.r0 = sw + 1; st.L = 0; st.L2 = L0; st.tau = 0.0; }
-    const int r0 = comp ? st.r0 : 0, L = comp ? st.L : 0, L2 = comp ? st.L2 : 0, rn = r0 + L;
-    int pr0, pL, pL2;
-    bool have_pf;
-    if (act == ACT_PRELOAD) { pr0 = sw + 1; pL = 0; pL2 = L0; have_pf = true; }
-    else {
-        have_pf = comp && (rn + L2 < n);
-        pr0 = rn; pL = L2; pL2 = have_pf ? ((n - (rn + L2) < SB) ? (n - (rn + L2)) : SB) : 0;
-    }
-    // ---- P1 ----
-    if (tid == 0) pollv = __hip_atomic_load(pollp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read at the end of the step
-    {
-        const double *__restrict__ Bb = have_pf ? (AB + ((size_t)pr0 * LD + pL)) : AB;
-        const double *__restrict__ Db = have_pf ? (AB + (size_t)(pr0 + pL) * LD) : AB;
-#pragma unroll
-        for (int cj = 0; cj < 4; ++cj)
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri) {
-                const int i = SB3_ROW(ri), j = SB3_COL(cj);
-                const bool okb = have_pf && (i < pL2) && (j < pL);
-                const bool okd = have_pf && ((low >> (ri * 4 + cj)) & 1u) && (i < pL2);
-                const double bv = Bb[okb ? off[ri][cj] : 0u];       // plain, L1-cached (see the invalidate below)
-                const double dv = Db[okd ? off[ri][cj] : 0u];
-                Bn[ri][cj] = okb ? bv : 0.0;
-                Dn[ri][cj] = okd ? dv : 0.0;
-            }
-        if (tid < 64) {
-            const bool okx = (act == ACT_PRELOAD) && (tid < L0);
-            const double xr = AB[okx ? ((size_t)sw * LD + 1 + tid) : 0];
-            xpre = (act == ACT_PRELOAD) ? (okx ? xr : 0.0) : xpre;
-        }
-        double vcj[4];
-#pragma unroll
-        for (int cj = 0; cj < 4; ++cj) vcj[cj] = vc[j0 + cj];
-#pragma unroll
-        for (int ri = 0; ri < 4; ++ri) {
-            double a = 0.0;
-#pragma unroll
-            for (int cj = 0; cj < 4; ++cj) a += Bc[ri][cj] * vcj[cj];
-            S.R1[jb][SB3_ROW(ri)] = a;
-        }
-        if (jb == 0) {
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri) S.x0[SB3_ROW(ri)] = Bc[ri][0];
-        }
-    }
-    lds_barrier();
-    // ---- P2 ----
-    if (tid < 64) {
-        const int i = tid;
-        double a = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) a += S.R1[q][i];
-        const double wi = item0 ? 0.0 : st.tau * a;
-        const double xc = item0 ? xpre : (S.x0[i] - wi * vc[0]);
-        const double xi = (i < L2) ? xc : 0.0;
-        double beta2, tau2;
-        const double vi = wave_house(xi, i, L2, &beta2, &tau2);
-        const double sdot = wave_sum(vi * wi);
-        S.w[i] = wi; vn[i] = vi;
-        if (i == 0) { S.sc[1] = beta2; S.sc[2] = tau2; S.sc[3] = sdot; }
-    }
-    lds_barrier();
-    const double beta2 = S.sc[1], tau2 = S.sc[2], sdot = S.sc[3];
-    // ---- P3 ----
-    double vni[4], vnj[4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x) { vni[x] = vn[SB3_ROW(x)]; vnj[x] = vn[j0 + x]; }
-    {
-#pragma unroll
-        for (int cj = 0; cj < 4; ++cj) {
-            double a = 0.0;
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri) a += vni[ri] * Bc[ri][cj];
-            S.R2[ib][j0 + cj] = a;
-        }
-#pragma unroll
-        for (int ri = 0; ri < 4; ++ri) {
-            double a = 0.0;
-#pragma unroll
-            for (int cj = 0; cj < 4; ++cj) a += Dc[ri][cj] * vnj[cj];
-            S.R3[jb][SB3_ROW(ri)] = a;
-        }
-#pragma unroll
-        for (int cj = 0; cj < 4; ++cj) {
-            double a = 0.0;
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri) a += (SB3_ROW(ri) != j0 + cj) ? Dc[ri][cj] * vni[ri] : 0.0;
-            S.R4[ib][j0 + cj] = a;
-        }
-    }
-    lds_barrier();
-    // ---- P4 ----
-    if (tid < 64) {
-        const int j = tid;
-        double a = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) a += S.R2[q][j];
-        S.z[j] = tau2 * (a - sdot * vc[j]);
-    } else if (tid < 128) {
-        const int i = tid - 64;
-        double a = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) a += S.R3[q][i] + S.R4[q][i];
-        const double pi = tau2 * a;
-        const double dot = wave_sum(pi * vn[i]);
-        S.pv[i] = pi + (-0.5 * tau2 * dot) * vn[i];
-    }
-    lds_barrier();
-    // ---- P5 ----
-    {
-        double wi[4], zj[4], vcj[4], pi[4], pj[4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            wi[x] = S.w[SB3_ROW(x)]; zj[x] = S.z[j0 + x]; vcj[x] = vc[j0 + x]; pi[x] = S.pv[SB3_ROW(x)]; pj[x] = S.pv[j0 + x];
-        }
-        double *__restrict__ Bb = AB + ((size_t)r0 * LD + L);
-        double *__restrict__ Db = AB + (size_t)rn * LD;
-#pragma unroll
-        for (int cj = 0; cj < 4; ++cj)
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri) {
-                const int i = SB3_ROW(ri), j = j0 + cj;
-                double bnew = Bc[ri][cj] - (wi[ri] * vcj[cj] + vni[ri] * zj[cj]);
-                if (j == 0) bnew = (i == 0) ? beta2 : 0.0;
-                if (i < L2 && j < L) Bb[off[ri][cj]] = bnew;
-                if (((low >> (ri * 4 + cj)) & 1u) && i < L2)
-                    Db[off[ri][cj]] = Dc[ri][cj] - (vni[ri] * pj[cj] + pi[ri] * vnj[cj]);
-            }
-        if (item0 && tid < L2) AB[(size_t)sw * LD + 1 + tid] = (tid == 0) ? beta2 : 0.0;
-    }
-    if (comp) { st.r0 = rn; st.L = L2; st.L2 = pL2; st.tau = tau2; }
-}
-
-__global__ __launch_bounds__(256) void sb2st_kernel_v6(int n, int npad, int batch, double *ABall, double *dall,
-                                                      double *eall, Sb6Ctl *ctl, int *status)
-{
-    __shared__ Sb3Lds S;
-    __shared__ int sh_mode;
-    __shared__ unsigned long long sh_pw;
-    constexpr int LD = 2 * SB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // blocks b and b+8 are observed to share an XCD (round-robin dispatch): pair them, then VERIFY
-    const int blk = blockIdx.x, grp = blk >> 4, rr = blk & 15;
-    const int chn = grp * 8 + (rr & 7), h = rr >> 3;
-    if (chn >= batch) return;
-    Sb6Ctl *C = ctl + chn;
-    // ---- handshake: 0 = exit, 1 = pair, 2 = solo ----
-    if (tid == 0) {
-        const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu;     // HW_REG_XCC_ID
-        const unsigned mine = (0x10u | xcc) << (8 * h);
-        const unsigned old = atomicOr(&C->pair, mine);
-        int mode = -1;
-        if (old & 0x80000000u) mode = 0;
-        for (int spin = 0; mode < 0 && spin < 400000; ++spin) {
-            const unsigned v = __hip_atomic_load(&C->pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v & 0x80000000u) { mode = 0; break; }
-            const unsigned ob = (v >> (8 * (h ^ 1))) & 0xffu;
-            if (ob & 0x10u) { mode = ((ob & 0xfu) == xcc) ? 1 : (h == 0 ? 2 : 0); break; }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        if (mode < 0) {                                   // partner did not show up: try to claim the channel
-            if (atomicCAS(&C->pair, mine, mine | 0x80000000u) == mine) mode = 2;
-            else {
-                const unsigned v = __hip_atomic_load(&C->pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned ob = (v >> (8 * (h ^ 1))) & 0xffu;
-                if (v & 0x80000000u) mode = 0;
-                else mode = ((ob & 0x10u) && (ob & 0xfu) == xcc) ? 1 : (h == 0 ? 2 : 0);
-            }
-        }
-        sh_mode = mode;
-    }
-    __syncthreads();
-    const int mode = sh_mode;
-    if (mode == 0) return;
-    if (mode == 2) { sb2st_v3_body<0>(n, npad, ABall, dall, eall, nullptr, (size_t)chn); return; }
-
-    // ---- pair mode ----
-    const int ib = lane & 15, jb = (lane >> 4) + 4 * wave;
-    const int j0 = 4 * jb;
-    unsigned off[4][4], low = 0;
-#pragma unroll
-    for (int cj = 0; cj < 4; ++cj)
-#pragma unroll
-        for (int ri = 0; ri < 4; ++ri) {
-            const int i = SB3_ROW(ri), j = j0 + cj;
-            off[ri][cj] = (unsigned)(j * (LD - 1) + i);
-            if (i >= j) low |= 1u << (ri * 4 + cj);
-        }
-    double *AB = ABall + (size_t)chn * ab_stride(npad);
-    const unsigned long long *pollp = &C->prog[h ^ 1];
-    unsigned long long *pubp = &C->prog[h];
-    int sw = h, state, done = 0, par = 0;
-    {
-        const int L0 = (n - 1 - sw < SB) ? (n - 1 - sw) : SB;
-        state = (sw < n - 2 && L0 >= 2) ? 1 : 0;
-    }
-    ChaseState st; st.r0 = 0; st.L = 0; st.L2 = 0; st.L3 = 0; st.tau = 0.0;
-    double xpre = 0.0;
-    unsigned long long pollv = 0, pw = 0;                 // pw: partner progress known to this workgroup
-    unsigned long long hist0 = ((unsigned long long)sw << 20), hist1 = hist0, hist2 = hist0;   // own progress pipeline
-    double B0[4][4], D0[4][4], B1[4][4], D1[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { B0[a][c] = 0.0; D0[a][c] = 0.0; B1[a][c] = 0.0; D1[a][c] = 0.0; }
-    bool failed = false;
-    const long long tstart = (long long)__builtin_amdgcn_s_memtime();
-    // One iteration = two super-steps in straight-line code with the register sets swapped (a run-time
-    // choice between the two instantiations would be a control-flow join with loads pending into
-    // different registers, which makes hipcc drain vmcnt(0) every step).
-#define SB6_ONE_STEP(PARITY, BA, DA, BB, DB)                                                                       \
-    {                                                                                                              \
-        const int act = (state == 1) ? ACT_PRELOAD : ((state == 2) ? ACT_ITEM0 : ACT_CHASE);                      \
-        const int need = ((act == ACT_PRELOAD) ? 0 : (act == ACT_ITEM0 ? 1 : done + 1)) + SB6_MARGIN;             \
-        if (!sb6_dep_ok(pw, sw, need)) {                                                                           \
-            const long long tw0 = (long long)__builtin_amdgcn_s_memtime();                                        \
-            __syncthreads();                       /* drain this workgroup's stores ... */                        \
-            if (tid == 0) {                                                                                        \
-                __hip_atomic_store(pubp, ((unsigned long long)sw << 20) | (unsigned)done, __ATOMIC_RELAXED,       \
-                                   __HIP_MEMORY_SCOPE_AGENT);      /* ... and publish the true progress */        \
-                unsigned long long v = 0;                                                                          \
-                int spin = 0;                                                                                      \
-                for (; spin < 8000000; ++spin) {                                                                   \
-                    v = __hip_atomic_load(pollp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                      \
-                    if (sb6_dep_ok(v, sw, need + SB6_HYST)) break;                                                 \
-                    __builtin_amdgcn_s_sleep(8);                                                                   \
-                }                                                                                                  \
-                if (spin >= 8000000) { v = SB6_FIN; atomicExch(&C->err, 1); if (status) atomicExch(status, BSP_ERR_HIP); } \
-                sh_pw = v;                                                                                         \
-                C->nwait[h] += 1;                                                                                  \
-                C->wcycles[h] += (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - tw0);             \
-            }                                                                                                      \
-            __syncthreads();                                                                                       \
-            pw = sh_pw;                                                                                            \
-            hist0 = hist1 = hist2 = ((unsigned long long)sw << 20) | (unsigned)done;                               \
-        }                                                                                                          \
-        /* L1 coherence: tiles are read with plain (L1-cached) loads; a line cached during sweep s is next   \
-           read during sweep s+2, after the partner rewrote it.  One L1 invalidate per sweep, completed      \
-           (vmcnt(0)) before the sweep's first load, removes every such line (a run WITHOUT it returns wrong \
-           spectra: measured).  sc1 loads instead cost +18%: tile rows straddle 128-B lines. */              \
-        if (act == ACT_PRELOAD) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");             \
-        superstep_v6<PARITY>(AB, S, tid, ib, j0, off, low, n, act, sw, st, xpre, pollp, pollv, BA, DA, BB, DB);  \
-        if (act == ACT_PRELOAD) state = 2;                                                                         \
-        else {                                                                                                     \
-            done = (act == ACT_ITEM0) ? 1 : done + 1;                                                              \
-            if (st.L2 > 0) state = 3;                                                                              \
-            else {                                                                                                 \
-                sw += 2; done = 0;                                                                                 \
-                const int Lnext = (n - 1 - sw < SB) ? (n - 1 - sw) : SB;                                           \
-                state = (sw < n - 2 && Lnext >= 2) ? 1 : 0;                                                        \
-            }                                                                                                      \
-        }                                                                                                          \
-        hist2 = hist1; hist1 = hist0; hist0 = ((unsigned long long)sw << 20) | (unsigned)done;                     \
-        if (tid == 0) {                                                                                            \
-            __hip_atomic_store(pubp, hist2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                           \
-            sh_pw = pollv;                                                                                         \
-        }                                                                                                          \
-        lds_barrier();                                                                                             \
-        pw = sh_pw;                                                                                                \
-    }
-    while (state != 0) {
-        SB6_ONE_STEP(0, B0, D0, B1, D1)
-        if (state == 0) break;
-        SB6_ONE_STEP(1, B1, D1, B0, D0)
-    }
-#undef SB6_ONE_STEP
-    (void)failed; (void)par;
-    __syncthreads();                                                      // all stores of this half are complete
-    if (tid == 0) {
-        C->tcycles[h] = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - tstart);
-        __hip_atomic_store(pubp, SB6_FIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (h == 0) {                                                         // half 0 writes d, e once both halves are done
-        if (tid == 0) {
-            int spin = 0;
-            for (; spin < 8000000; ++spin) {
-                if (__hip_atomic_load(pollp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= SB6_FIN) break;
-                __builtin_amdgcn_s_sleep(8);
-            }
-            if (spin >= 8000000) { atomicExch(&C->err, 2); if (status) atomicExch(status, BSP_ERR_HIP); }
-        }
-        __syncthreads();
-        double *d = dall + (size_t)chn * npad, *e = eall + (size_t)chn * npad;
-        for (int j = tid; j < n; j += 256) {
-            d[j] = ld_sc1(AB + (size_t)j * LD);
-            e[j] = (j < n - 1) ? ld_sc1(AB + (size_t)j * LD + 1) : 0.0;
-        }
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // v7: TWO SWEEPS PER PASS WITH ON-CHIP FORWARDING (halves the HBM traffic of bulge chasing).
@@ -1445,7 +1123,7 @@ __device__ __forceinline__ void superstep_v7B(double *__restrict__ AB, Sb7Shared
 template <int DIAG>
 __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, int batch, double *ABall, double *dall, double *eall,
                                                        int *status, long long *diag, Sb8Ctl *ctl, int P, int margin, int hyst,
-                                                       int lead)
+                                                       int lead, int force_abort)
 {
     Diag7 dg;
     if (DIAG) { for (int q = 0; q < 12; ++q) dg.acc[q] = 0; dg.tlast = (long long)__builtin_amdgcn_s_memtime(); }
@@ -1474,7 +1152,8 @@ __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, int batc
             for (int q = 0; q < P; ++q) full |= 0x10ull << (8 * q);
             unsigned long long v = atomicOr(&C->hs, mine) | mine;
             for (int spin = 0; !(v & (SB8_COMMIT | SB8_ABORT)); ++spin) {
-                if ((v & full) == full) atomicCAS(&C->hs, v, v | SB8_COMMIT);
+                if (force_abort == 1) atomicCAS(&C->hs, v, v | SB8_ABORT);           // test hook: the time-out branch
+                else if ((v & full) == full) atomicCAS(&C->hs, v, v | SB8_COMMIT);
                 else if (spin > 400000) atomicCAS(&C->hs, v, v | SB8_ABORT);
                 else __builtin_amdgcn_s_sleep(4);
                 v = __hip_atomic_load(&C->hs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1484,6 +1163,7 @@ __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, int batc
             else {
                 bool same = true;
                 for (int q = 1; q < P; ++q) same = same && (((v >> (8 * q)) & 0xfu) == (v & 0xfu));
+                if (force_abort == 2) same = false;                                  // test hook: the cross-XCD branch
                 mode = same ? 1 : ((w == 0) ? 2 : 0);
             }
             SH.mode = mode;
@@ -1580,49 +1260,19 @@ __global__ __launch_bounds__(512) void sb2st_kernel_v7(int n, int npad, int batc
 
 size_t sb2st_ctl_bytes(int batch)
 {
-    return (size_t)batch * (sizeof(Sb8Ctl) > sizeof(Sb6Ctl) ? sizeof(Sb8Ctl) : sizeof(Sb6Ctl));
+    return (size_t)batch * sizeof(Sb8Ctl);
 }
 
 int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st, int *d_status,
                  void *ctl)
 {
     if (b != SB) return BSP_ERR_ARG;
-    static int ver = -1;
-    if (ver < 0) { const char *e = getenv("BSP_SB2ST_VERSION"); ver = e ? atoi(e) : 8; }
-    // 8 (default): paired two-sweep workgroups; 7: one two-sweep workgroup per channel; 6: paired one-sweep
-    // workgroups; 3: one one-sweep workgroup per channel (the generations DESIGN.md 4.1 describes; v1, v2, v4 are in
-    // the history only)
-    if (ver != 3 && ver != 6 && ver != 7 && ver != 8) return BSP_ERR_ARG;
-    if (ver == 6) {
-        static Sb6Ctl *s_ctl = nullptr;
-        static int cap = 0;
-        Sb6Ctl *d_ctl = static_cast<Sb6Ctl *>(ctl);
-        if (!d_ctl) {
-            if (cap < batch) {
-                if (s_ctl) hipFree(s_ctl);
-                BSP_HIP(hipMalloc(reinterpret_cast<void **>(&s_ctl), (size_t)batch * sizeof(Sb6Ctl)));
-                cap = batch;
-            }
-            d_ctl = s_ctl;
-        }
-        BSP_HIP(hipMemsetAsync(d_ctl, 0, (size_t)batch * sizeof(Sb6Ctl), st));
-        const int nblk = ((batch + 7) / 8) * 16;
-        hipLaunchKernelGGL(sb2st_kernel_v6, dim3(nblk), dim3(256), 0, st, n, npad, batch, d_AB, d_d, d_e, d_ctl, d_status);
-        if (getenv("BSP_SB2ST_CHECK")) {
-            std::vector<Sb6Ctl> hc(batch);
-            BSP_HIP(hipStreamSynchronize(st));
-            BSP_HIP(hipMemcpy(hc.data(), d_ctl, (size_t)batch * sizeof(Sb6Ctl), hipMemcpyDeviceToHost));
-            int nerr = 0, nsolo = 0;
-            for (auto &c : hc) { nerr += c.err != 0; nsolo += (c.pair >> 31) || (((c.pair >> 8) ^ c.pair) & 0xf); }
-            double nw[2] = {0, 0}, wc[2] = {0, 0}, tc[2] = {0, 0};
-            for (auto &c : hc) for (int q = 0; q < 2; ++q) { nw[q] += c.nwait[q]; wc[q] += c.wcycles[q]; tc[q] += c.tcycles[q]; }
-            fprintf(stderr, "bspatom: sb2st v6: %d channels, %d solo, %d errors; per channel: waits %.0f/%.0f, waiting share %.1f%%/%.1f%%, Mcycles %.1f/%.1f\n",
-                    batch, nsolo, nerr, nw[0] / batch, nw[1] / batch, 100 * wc[0] / (tc[0] + 1), 100 * wc[1] / (tc[1] + 1),
-                    tc[0] / batch / 1e6, tc[1] / batch / 1e6);
-            if (nerr) return BSP_ERR_HIP;
-        }
-    }
-    else if (ver == 7 || ver == 8) {
+    const int ver = opts().sb2st_version;
+    // 8 (default): two-sweep workgroups in rings of P per channel; 7: one two-sweep workgroup per channel; 3: one
+    // one-sweep workgroup per channel (an independent implementation of the same chase, kept as the cross-check of
+    // tests/test_gpu_solve.py::test_sb2st_fallback_paths); v1, v2, v4, v6 are in the history only
+    if (ver != 3 && ver != 7 && ver != 8) return BSP_ERR_ARG;
+    if (ver == 7 || ver == 8) {
         // 7: one workgroup per channel; 8: two (the partner CU runs the two sweeps in between), v6's pairing
         static bool attr7 = false;
         if (!attr7) {
@@ -1633,12 +1283,12 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
             attr7 = true;
         }
         static int *d_chk = nullptr;
-        const bool chk = getenv("BSP_SB2ST_CHECK") != nullptr;
+        const bool chk = opts().sb2st_check != 0;
         if (chk && !d_chk) BSP_HIP(hipMalloc(reinterpret_cast<void **>(&d_chk), sizeof(int)));
         if (chk) BSP_HIP(hipMemsetAsync(d_chk, 0, sizeof(int), st));
         static Sb8Ctl *s_ctl7 = nullptr;
-        static int cap7 = 0, ring_env = -1;
-        if (ring_env < 0) { const char *e = getenv("BSP_SB2ST_RING"); ring_env = e ? atoi(e) : 0; }
+        static int cap7 = 0;
+        const int ring_env = opts().sb2st_ring;
         Sb8Ctl *d_ctl = nullptr;
         // ring size: as many workgroups per channel as the chip has CUs for (each needs a whole CU), at most 8;
         // 128 channels -> pairs, 32 channels -> rings of 8 (16 sweeps in flight per channel)
@@ -1663,18 +1313,14 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
         }
         const int nblk = (ver == 8) ? ((batch + 7) / 8) * 8 * P : batch;
         const size_t lds = (sizeof(Sb7Shared) + 1023) / 1024 * 1024;
-        static int diag7 = -1, margin = SB6_MARGIN, lead = 16, hyst = 2;   // measured: holds 13k -> 1.6k per channel with the lead   // measured: 243 ms (hyst 2) .. 258 ms (hyst 16)
-        if (diag7 < 0) {
-            const char *e = getenv("BSP_SB2ST_DIAG"); diag7 = e ? atoi(e) : 0;
-            if ((e = getenv("BSP_SB2ST_MARGIN"))) margin = atoi(e);
-            if ((e = getenv("BSP_SB2ST_HYST"))) hyst = atoi(e);
-            if ((e = getenv("BSP_SB2ST_LEAD"))) lead = atoi(e);
-        }
+        // measured: holds 13k -> 1.6k per channel with the lead 16; 243 ms (hyst 2) .. 258 ms (hyst 16)
+        const int diag7 = opts().sb2st_diag, margin = opts().sb2st_margin, lead = opts().sb2st_lead, hyst = opts().sb2st_hyst;
+        const int fab = opts().sb2st_force_abort;
         if (diag7) {
             long long *dbuf = nullptr, h[96];
             BSP_HIP(hipMalloc(reinterpret_cast<void **>(&dbuf), sizeof(h)));
             hipLaunchKernelGGL(sb2st_kernel_v7<1>, dim3(nblk), dim3(512), lds, st, n, npad, batch, d_AB, d_d, d_e,
-                               chk ? d_chk : d_status, dbuf, d_ctl, P, margin, hyst, lead);
+                               chk ? d_chk : d_status, dbuf, d_ctl, P, margin, hyst, lead, fab);
             BSP_HIP(hipStreamSynchronize(st));
             BSP_HIP(hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost));
             hipFree(dbuf);
@@ -1688,7 +1334,7 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
             }
         } else
         hipLaunchKernelGGL(sb2st_kernel_v7<0>, dim3(nblk), dim3(512), lds, st, n, npad, batch, d_AB, d_d, d_e,
-                           chk ? d_chk : d_status, (long long *)nullptr, d_ctl, P, margin, hyst, lead);
+                           chk ? d_chk : d_status, (long long *)nullptr, d_ctl, P, margin, hyst, lead, fab);
         if (chk) {
             int hv = 0;
             BSP_HIP(hipStreamSynchronize(st));
@@ -1716,8 +1362,7 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
         }
     }
     else if (ver == 3) {
-        static int diag = -1;
-        if (diag < 0) { const char *e = getenv("BSP_SB2ST_DIAG"); diag = e ? atoi(e) : 0; }
+        const int diag = opts().sb2st_diag;
         if (!diag) hipLaunchKernelGGL(sb2st_kernel_v3<0>, dim3(batch), dim3(256), 0, st, n, npad, d_AB, d_d, d_e, (long long *)nullptr);
         else if (diag == 2) hipLaunchKernelGGL(sb2st_kernel_v3<2>, dim3(batch), dim3(256), 0, st, n, npad, d_AB, d_d, d_e, (long long *)nullptr);
         else if (diag == 3) hipLaunchKernelGGL(sb2st_kernel_v3<3>, dim3(batch), dim3(256), 0, st, n, npad, d_AB, d_d, d_e, (long long *)nullptr);

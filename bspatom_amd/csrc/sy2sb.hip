@@ -585,8 +585,7 @@ void sy2sb_carve(void *base, int npad, int nb, int batch, Sy2sbWork *w)
 template <int RPT>
 static void launch_pq(int npad, int r0, int c0, int batch, double *A, double *buf, double *tau, hipStream_t st)
 {
-    static int use2 = -1;
-    if (use2 < 0) { const char *e = getenv("BSP_PANEL_QR"); use2 = e ? (atoi(e) == 2) : 1; }
+    const int use2 = opts().panel_qr == 2;
     if (use2 && RPT <= 8) {
         const size_t lds = (size_t)(2 * CW2 * PQ_THREADS * RPT + 128) * sizeof(double);
         static bool attr[17] = {};
@@ -679,8 +678,7 @@ static int sy2sb_panel(int npad, int batch, double *d_A, const Sy2sbWork &w, hip
             // drain, which is when the panel stream's small kernels (T, W ...) find a place (BSP_SY2SB_SEGS)
             // (measured at 128 channels, n = 4096: 1 launch 307-308 ms, 2: 305, 3: 302-303, 4: 303-304, 6: 306, 8: 307;
             // small trailing matrices -- fewer than six fills of the GPU -- stay in one launch)
-            static int nseg_env = -1;
-            if (nseg_env < 0) { const char *e = getenv("BSP_SY2SB_SEGS"); nseg_env = e ? atoi(e) : 0; }
+            const int nseg_env = opts().sy2sb_segs;
             const long nbt = (m + 127) / 128, wgs = nbt * (nbt + 1) / 2 * batch;
             const int nseg2 = (nseg_env >= 1) ? nseg_env : ((wgs >= 6 * 512) ? 3 : 1);
             for (int sg = 0; sg < nseg2; ++sg)
@@ -715,12 +713,13 @@ int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipS
     constexpr int MAXG = 4;
     static Sy2sbLane lanes[MAXG];
     static hipEvent_t fork = nullptr;
-    static int lookahead = -1, groups = 2;
-    if (lookahead < 0) {
-        const char *e = getenv("BSP_SY2SB_LOOKAHEAD"); lookahead = e ? atoi(e) : 1;
-        if ((e = getenv("BSP_SY2SB_GROUPS"))) groups = atoi(e);
-        if (groups < 1) groups = 1;
-        if (groups > MAXG) groups = MAXG;
+    static bool lanes_ready = false;
+    const int lookahead = opts().sy2sb_lookahead;
+    int groups = opts().sy2sb_groups;
+    if (groups < 1) groups = 1;
+    if (groups > MAXG) groups = MAXG;
+    if (!lanes_ready) {
+        lanes_ready = true;
         int plo = 0, phi = 0;                      // the latency-bound panel work gets the high-priority queue
         BSP_HIP(hipDeviceGetStreamPriorityRange(&plo, &phi));
         // (Giving the panel streams compute units of their own through CU masks -- a panel-QR workgroup needs a whole

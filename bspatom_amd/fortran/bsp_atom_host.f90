@@ -5,7 +5,12 @@
 !  writes stdout, Enl.dat and wf_n0.dat in the reference's formats
 !  (src/matrices.f90:239-240,256-265,388-391; src/Bsp_Atom.f90:118-146).  KIND_PI = 0 ends there;
 !  KIND_PI >= 3 also reproduces the state limits and Eigenvec_All.dat (src/matrices.f90:290-378);
-!  the photo-ionisation branches that follow SOLVE_SYSTEM in the reference are not part of this host.
+!  KIND_PI = 1, 2 (one-photon, length / velocity gauge) continue through TRANS_AMP and CROSS_SECTIONS
+!  (src/PhotoIon.f90:50-107, 274-468) to CSs/CrossSection_Len.dat / CSs/CrossSection_Vel.dat, the dipole
+!  matrix elements coming from bspatom_dipole_elements.  Two variables CROSS_SECTIONS reads are set by the
+!  reference for KIND_PI >= 3 only (Enl(n0,l0) -> E_ini(n0) here; the loop bound n1_max -> n1_fin), and its
+!  T_fi(nf,il) is addressed with the channel l_fin it was allocated for; see DESIGN.md.
+!  The Gaussian / LG-beam branches that follow SOLVE_SYSTEM for KIND_PI >= 3 are not part of this host.
       MODULE BSPATOM_C
       USE ISO_C_BINDING
       IMPLICIT NONE
@@ -57,6 +62,14 @@
           INTEGER(C_INT), VALUE :: l, n0, cnt
           REAL(C_DOUBLE), INTENT(OUT) :: Z(*)
         END FUNCTION
+        INTEGER(C_INT) FUNCTION bspatom_dipole_elements(prob, l_ini, n0_ini, l_fin, n0_fin, cnt, a, D)                    &
+     &                  BIND(C, NAME='bspatom_dipole_elements')
+          IMPORT :: C_INT, C_PTR, C_DOUBLE
+          TYPE(C_PTR), VALUE :: prob
+          INTEGER(C_INT), VALUE :: l_ini, n0_ini, l_fin, n0_fin, cnt
+          REAL(C_DOUBLE), INTENT(IN) :: a(3)
+          REAL(C_DOUBLE), INTENT(OUT) :: D(*)
+        END FUNCTION
         INTEGER(C_INT) FUNCTION bspatom_write_wf(prob, c, npts, r, u) BIND(C, NAME='bspatom_write_wf')
           IMPORT :: C_INT, C_PTR, C_DOUBLE
           TYPE(C_PTR), VALUE :: prob
@@ -99,6 +112,12 @@
       REAL(DP), ALLOCATABLE :: Zl(:,:)
       REAL(DP), ALLOCATABLE :: En(:), ci(:), r(:), u(:)
       INTEGER(C_INT32_T), ALLOCATABLE :: info(:)
+!     KIND_PI = 1, 2: TRANS_AMP / CROSS_SECTIONS (names as in PhotoIon.f90)
+      INTEGER :: lf, mf, l0, m0, nf
+      REAL(DP) :: T3ja, T3jb, c0, c1, c2, An, d1, d2, csl, M_au, cc0, cc1, Ef, avec(3)
+      REAL(DP), ALLOCATABLE :: dip(:), T_fi(:)
+      REAL(DP), PARAMETER :: PI = 3.141592653589793238462643D0, c_au = 137.03599913815D0, a_au = 5.29177249D-9
+      REAL(DP), EXTERNAL :: W3J
 
       WRITE(6,'(A64)') 'PROGRAM TO CALCULATE ELECTRONIC STRUCTURE AND PI CROSS SECTIONS,'
       WRITE(6,'(A17,/)') '  USING B-SPLINES'
@@ -114,10 +133,17 @@
       b0 = 0.D0; afocus = 0.D0; nEpts = 10; Eref = 0.D0; nthpts = 1; nphpts = 1; ncyc = 0
       bx = 0.D0; B0z = 0.D0; t_delay = 0.D0; ncyc2 = 0; Eph2 = 0.D0; A0x = 0.D0; A0y = 0.D0; A0z = 1.D0
       READ(5,VARS_FIELD)
+      lmax = MAX(lmax, l_fin)                          ! ReadInputs.f90:87
       IF( KIND_PI == 1 .OR. KIND_PI == 2 ) THEN
-        WRITE(6,*) 'bsp_atom_host: KIND_PI = 1, 2 continue into TRANS_AMP, which is not on the MI355X hot path'
-        STOP 2
+!       SEL_LM, dipolar case (grid.f90:128-143): final channels l0-1 (if it can carry m0) and l0+1; TRANS_AMP takes the last
+        lf = l_ini + 1; mf = m_ini
+        IF( lf > lmax ) THEN
+          WRITE(6,*) 'bsp_atom_host: l_fin = l_ini + 1 is beyond lmax of the input (the reference reads an unallocated ci_fin)'
+          STOP 2
+        END IF
       END IF
+!     Bsp_Atom.f90:59-60: the output directory of the cross-section files exists from the start
+      CALL EXECUTE_COMMAND_LINE('mkdir -p CSs')
 
       CALL bspatom_input_defaults(inp)
       inp%kind_grid = KIND_GRID; inp%k = k; inp%ka = ka; inp%nfun = nfun
@@ -251,12 +277,107 @@
         END DO
         CLOSE(80)
       END IF
+      IF( KIND_PI == 1 .OR. KIND_PI == 2 ) THEN
+!       final-state window at l = l_fin (matrices.f90:272-283)
+        l0 = l_ini; m0 = m_ini
+        IF( Emax_fin == -1.0D0 ) Emax_fin = En(lf*nfun+nfun)
+        n0_fin = -1; n1_fin = -1
+        DO i = 1, nfun
+          IF( En(lf*nfun+i) < 0.D0 ) n0_fin = i
+          IF( En(lf*nfun+i) <= Emax_fin ) n1_fin = i
+        END DO
+        n0_fin = MIN(n0_fin+1, nfun-1)
+        WRITE(6,'(/,A26,I2,A3,X,2I4)') 'LIMITS FOR FINAL STATE (l=', lf, ') :', n0_fin, n1_fin
+        IF( n1_fin + 1 > nfun .OR. n1_fin < n0_fin ) THEN
+          WRITE(6,*) 'bsp_atom_host: the density-of-states factor needs E_fin(n1_fin+1); lower Emax_fin'
+          STOP 2
+        END IF
+!       TRANS_AMP (PhotoIon.f90:36-107): T_fi(n) = An c0 <c_fin(n)| c1 rij1 + c2 rij2 |c_ini>
+        WRITE(6,'(/,A33)') 'Calculating Transition Amplitudes'
+        WRITE(6,'(A14,3I3)') 'Initial State:', n0_ini+l0, l0, m0
+        T3ja = W3J(lf,1,l0,-mf,mph,m0)
+        IF( KIND_PI == 1 ) THEN
+          T3jb = W3J(lf,1,l0,0,0,0)
+          c1 = (-1.D0)**(lf+l0+mf) * SQRT( DBLE((2*lf+1)*(2*l0+1)) ) * T3ja * T3jb
+          c0 = 1.0D0
+          avec = (/ c1, 0.D0, 0.D0 /)                  ! A = c1 * int B r B
+        ELSE
+          c0 = SQRT(DBLE(l0 + 1)) * T3ja
+          c1 = DBLE(l0 + 1); c2 = -1.D0                ! lf = l0 + 1
+          avec = (/ 0.D0, c1, c2 /)                    ! A = c1 * int B B / r + c2 * int B B'
+        END IF
+        ALLOCATE( dip(n1_fin-n0_fin+1), T_fi(n0_fin:n1_fin) )
+        rc = bspatom_dipole_elements(prob, INT(l0,C_INT), INT(n0_ini,C_INT), INT(lf,C_INT), INT(n0_fin,C_INT),            &
+     &                               INT(n1_fin-n0_fin+1,C_INT), avec, dip)
+        IF( rc /= 0 ) THEN
+          WRITE(6,*) 'bsp_atom_host: bspatom_dipole_elements failed, code ', rc
+          STOP 1
+        END IF
+        DO ni = n0_fin, n1_fin
+          An = SQRT( 2.D0 / (En(lf*nfun+ni+1) - En(lf*nfun+ni-1)) )
+          T_fi(ni) = An * c0 * dip(ni-n0_fin+1)
+        END DO
+!       CROSS_SECTIONS (PhotoIon.f90:274-468), plane-wave branches
+        WRITE(6,'(/,A26)') 'Calculating Cross Sections'
+        WRITE(6,*) 'E0=', En(l0*nfun+n0_ini)
+        M_au = (a_au**2) * 1.0D18
+        cc0 = 4.D0 * (PI**2) / (c_au)
+        cc1 = 1.D0 / DBLE(2*l0 + 1)
+        IF( KIND_PI == 1 ) THEN
+          OPEN( UNIT=30, FILE='CSs/CrossSection_Len.dat', ACTION='WRITE' )
+        ELSE
+          OPEN( UNIT=30, FILE='CSs/CrossSection_Vel.dat', ACTION='WRITE' )
+        END IF
+        DO nf = n0_fin, n1_fin
+          d1 = En(lf*nfun+nf) - En(l0*nfun+n0_ini)
+          IF( KIND_PI == 2 ) d1 = 1.D0 / d1
+          Ef = En(lf*nfun+nf)
+          d2 = T_fi(nf)**2
+          csl = M_au * cc0 * cc1 * d1 * d2
+          WRITE(30,400) Ef, csl
+        END DO
+        CLOSE(30)
+      END IF
       CALL bspatom_problem_destroy(prob)
-      IF( KIND_PI == 0 ) WRITE(6,'(/,A17)') 'Program Finished!'
+      IF( KIND_PI <= 2 ) WRITE(6,'(/,A17)') 'Program Finished!'
 
 100   FORMAT(/,T2,A5,I2)
 110   FORMAT(T2,A26,/)
 120   FORMAT(T5,A1,T9,A11)
 200   FORMAT(T2,I4,T8,G22.15)
 300   FORMAT(I5,5000G20.10)
+400   FORMAT(2G20.10E3)
       END PROGRAM BSP_ATOM_MI355X
+
+!     Wigner 3j symbol for integer arguments: Racah's sum with log-factorials, the smallest exponent taken out of the
+!     alternating sum (the scheme of the reference's THREE_J, Funs_WignerSymbols.for:1-62, so the two agree to rounding)
+      FUNCTION W3J(j1, j2, j3, m1, m2, m3) RESULT(w)
+      IMPLICIT NONE
+      INTEGER, PARAMETER :: DP = KIND(1.0D0)
+      INTEGER, INTENT(IN) :: j1, j2, j3, m1, m2, m3
+      REAL(DP) :: w, lf(0:200), delta, g, acc, ex
+      INTEGER :: i, z, zmin, zmax
+      w = 0.D0
+      IF( m1 + m2 + m3 /= 0 ) RETURN
+      IF( j1 + j2 + j3 + 1 > 200 ) RETURN
+      lf(0) = 0.D0
+      DO i = 1, j1 + j2 + j3 + 1
+        lf(i) = lf(i-1) + LOG(DBLE(i))
+      END DO
+      zmin = MAX(0, j2 - j3 - m1, j1 + m2 - j3)
+      zmax = MIN(j1 + j2 - j3, j1 - m1, j2 + m2)
+      IF( zmax < zmin ) RETURN
+      delta = 0.5D0 * ( lf(j1+j2-j3) + lf(j3+j1-j2) + lf(j3+j2-j1) - lf(j1+j2+j3+1)                                      &
+     &                + lf(j1+m1) + lf(j1-m1) + lf(j2+m2) + lf(j2-m2) + lf(j3+m3) + lf(j3-m3) )
+      g = 250.D0
+      DO z = zmin, zmax
+        ex = lf(z) + lf(j1+j2-j3-z) + lf(j1-m1-z) + lf(j2+m2-z) + lf(j3-j2+m1+z) + lf(j3-j1-m2+z)
+        g = MIN(g, ex)
+      END DO
+      acc = 0.D0
+      DO z = zmin, zmax
+        ex = lf(z) + lf(j1+j2-j3-z) + lf(j1-m1-z) + lf(j2+m2-z) + lf(j3-j2+m1+z) + lf(j3-j1-m2+z)
+        acc = acc + (-1.D0)**z * EXP(-(ex - g))
+      END DO
+      w = (-1.D0)**(j1-j2-m3) * EXP(delta - g) * acc
+      END FUNCTION W3J

@@ -10,27 +10,29 @@ from . import capi
 from .namelist import read_namelists
 
 
-def fortran_g(v, w, d):
-    """Fortran Gw.d edit descriptor (F2008 10.7.5.2.2) for a real value, as gfortran/flang print it."""
+def fortran_g(v, w, d, e=2):
+    """Fortran Gw.d (e = 2) or Gw.dEe edit descriptor (F2008 10.7.5.2.2) for a real value, as gfortran/flang print it:
+    F editing with e + 2 trailing blanks inside the range, else 0.dddE+xx with e exponent digits."""
+    pad = " " * (e + 2)
     if v == 0.0:
         body = "%.*f" % (d - 1, 0.0)
-        return (body + "    ").rjust(w)
-    a = abs(v)
+        return (body + pad).rjust(w)
+    return _fortran_g_tail(v, w, d, e, pad, abs(v))
+
+
+def _fortran_g_tail(v, w, d, edig, pad, a):
     e = math.floor(math.log10(a)) + 1
-    # rounding may push the value into the next decade
     if float("%.*e" % (d - 1, a)) >= 10.0 ** e:
         e += 1
     if 0 <= e <= d:
         body = "%.*f" % (d - e, v)
-        if body.startswith("0."):
-            pass
-        return (body + "    ").rjust(w)
+        return (body + pad).rjust(w)
     m = "%.*E" % (d - 1, v)            # d.ddddE+xx -> 0.ddddd E+(xx+1)
     mant, ex = m.split("E")
     sign = "-" if mant.startswith("-") else ""
     digits = mant.replace("-", "").replace(".", "")
     ex = int(ex) + 1
-    return ("%s0.%sE%+03d" % (sign, digits, ex)).rjust(w)
+    return ("%s0.%sE%+0*d" % (sign, digits, edig + 1, ex)).rjust(w)
 
 
 def kind_pi_from_namelist(text):
@@ -39,9 +41,6 @@ def kind_pi_from_namelist(text):
 
 def input_from_namelist(text):
     nl = read_namelists(text)
-    if nl["vars_field"].get("kind_pi", 0) in (1, 2):
-        raise ValueError("KIND_PI = 1, 2 (one-photon cross sections) continue into TRANS_AMP, which is not on the "
-                         "MI355X hot path; use KIND_PI = 0 or >= 3 (SOLVE_SYSTEM only)")
     kw = {}
     kw.update(nl["vars_bsp"]); kw.update(nl["vars_tise"])
     return capi.make_input(**kw)
@@ -156,9 +155,13 @@ def run(text, outdir=".", device=0, npts=10000):
     if lim is not None:
         out.append("n1_max =%5d" % lim.n1_max)                                          # '(A8,I5)'
         write_eigenvec_all(os.path.join(outdir, "Eigenvec_All.dat"), prob, prob.lmax, lim.n1_max)
-    if kind_pi == 0:
-        out.append("\nProgram Finished!")          # KIND_PI >= 3 continues into the photo-ionisation branch in the reference
     prob.close()
+    os.makedirs(os.path.join(outdir, "CSs"), exist_ok=True)            # Bsp_Atom.f90:59-60 (`mkdir CSs` at start-up)
+    if kind_pi in (1, 2):                                              # Bsp_Atom.f90:77-92: TRANS_AMP, CROSS_SECTIONS
+        r = cross_sections(text, outdir=outdir, device=device)
+        out.append("\n" + r["stdout"])
+    if kind_pi in (0, 1, 2):
+        out.append("\nProgram Finished!")          # KIND_PI >= 3 continues into the Gaussian / LG-beam branch in the reference
     return E, c, "\n".join(out)
 
 
@@ -318,3 +321,112 @@ def trans_amp(text, device=0):
            "Initial State:%3d%3d%3d" % (n0 + l0, l0, m0)]                              # '(A14,3I3)'
     prob.close()
     return dict(E=E, l_fin=lf, m_fin=mf, n0_fin=n0f, n1_fin=n1f, T_fi=T, stdout="\n".join(out))
+
+
+# a.u. -> Mb and the speed of light of the reference (Modules.f90:12)
+C_AU = 137.03599913815
+A_AU = 5.29177249e-9
+
+
+def cross_sections(text, outdir=".", device=0):
+    """KIND_PI = 1, 2 to the end of CROSS_SECTIONS (PhotoIon.f90:274-468): `CSs/CrossSection_Len.dat` (length gauge) or
+    `CSs/CrossSection_Vel.dat` (velocity gauge), one record FORMAT(2G20.10E3) `E_fin(nf), sigma(nf)` per final state
+    nf = n0_fin .. n1_fin, sigma = M_au c0 c1 d1 T_fi(nf)^2 with M_au = a_au^2 1e18 (Mb), c0 = 4 pi^2 / c_au,
+    c1 = 1/(2 l0 + 1), d1 = E_fin(nf) - E_ini(n0) (length) or its reciprocal (velocity) (:316-322, :387-394, :403).
+    Two deviations from the reference AS WRITTEN, both where it reads variables SOLVE_SYSTEM sets for KIND_PI >= 3
+    only: the loop `DO nf = n0_fin, n1_max` (:385) runs to n1_fin (the records are written for nf <= n1_fin anyway,
+    :408), and the printed `E0=` (:302-303, Enl(n0,l0): unallocated here) is E_ini(n0).  The fixtures
+    tests/golden/cs_*.npz come from the reference's own routine called with those two values set by the dump driver.
+    T_fi is squared, so the arbitrary eigenvector signs drop out."""
+    r = trans_amp(text, device=device)
+    nl = read_namelists(text)
+    kind_pi = int(nl["vars_field"]["kind_pi"])
+    n0 = int(nl["vars_tise"].get("n0_ini", 1)); l0 = int(nl["vars_tise"].get("l_ini", 0))
+    E_ini = r["E"][l0]; E_fin = r["E"][r["l_fin"]]
+    m_au = (A_AU ** 2) * 1.0e18
+    c0 = 4.0 * (math.pi ** 2) / C_AU
+    c1 = 1.0 / float(2 * l0 + 1)
+    rows = []
+    for nf in range(r["n0_fin"], r["n1_fin"] + 1):
+        d1 = E_fin[nf - 1] - E_ini[n0 - 1]
+        if kind_pi == 2:
+            d1 = 1.0 / d1
+        d2 = r["T_fi"][nf - r["n0_fin"]] ** 2
+        rows.append((E_fin[nf - 1], m_au * c0 * c1 * d1 * d2))
+    os.makedirs(os.path.join(outdir, "CSs"), exist_ok=True)
+    name = "CrossSection_Len.dat" if kind_pi == 1 else "CrossSection_Vel.dat"
+    with open(os.path.join(outdir, "CSs", name), "w") as f:
+        for ef, cs in rows:
+            f.write(fortran_g(ef, 20, 10, 3) + fortran_g(cs, 20, 10, 3) + "\n")
+    r["rows"] = rows
+    r["file"] = os.path.join("CSs", name)
+    r["stdout"] = r["stdout"] + "\n\nCalculating Cross Sections\n E0= %s" % repr(float(E_ini[n0 - 1]))
+    return r
+
+
+# ---- CSs/MatElem_All.dat: the coupling file the sibling TDSE tools read (SURVEY 8(f).3) ------------------------------
+def write_matelem_all(path, n1_max, zT):
+    """`CSs/MatElem_All.dat` as TRANS_AMP writes it (PhotoIon.f90:255-266): list-directed header `n1_max nbra nket`, then
+    for ibra = 1..nbra, jket = ibra..nket one record FORMAT(2I8,X,20G20.10) `ibra, jket, (Re, Im of zT(ibra,jket,i),
+    i = 1..ncomp)`.  zT: complex array (nbra, nket, ncomp), upper triangle used.  The reader is READ_COUP
+    (ReadInputs.f90:324-366)."""
+    nbra, nket, ncomp = zT.shape
+    with open(path, "w") as f:
+        f.write(" %d %d %d\n" % (n1_max, nbra, nket))
+        for ib in range(nbra):
+            for jk in range(ib, nket):
+                rec = "%8d%8d " % (ib + 1, jk + 1)
+                for i in range(ncomp):
+                    z = complex(zT[ib, jk, i])
+                    rec += fortran_g(z.real, 20, 10) + fortran_g(z.imag, 20, 10)
+                f.write(rec + "\n")
+
+
+def read_matelem_all(path, nfields=1):
+    """Reads the file back the way READ_COUP does (ReadInputs.f90:324-366): list-directed `n1_max nbra nket`, then
+    list-directed records `ibra jket f(1:2 nfields)`; returns (n1_max, zHint[nbra][nket][nfields]), upper triangle."""
+    import numpy as np
+    with open(path) as f:
+        n1_max, nbra, nket = (int(t) for t in f.readline().split())
+        z = np.zeros((nbra, nket, nfields), dtype=np.complex128)
+        for ni in range(nbra):
+            for nj in range(ni, nket):
+                t = f.readline().replace(",", " ").split()
+                if len(t) < 2 + 2 * nfields:
+                    raise ValueError("Error Reading Couplings File")
+                ib, jk = int(t[0]), int(t[1])
+                v = [float(x.replace("D", "E")) for x in t[2: 2 + 2 * nfields]]
+                for i in range(nfields):
+                    z[ib - 1, jk - 1, i] = complex(v[2 * i], v[2 * i + 1])
+    return n1_max, z
+
+
+def dipole_matelem(prob, channels, n1_max, kind_pi=1, mph=0):
+    """Coupling matrix of the one-photon dipole operator between the states (l, n = 1..n1_max) of `channels` (a list of
+    (l, m)), laid out as TRANS_AMP lays out zT_fi for the beam cases: row / column index = il * n1_max + n (il = position
+    in `channels`), one component.  <n l m| c1 r |n' l' m'> in the length gauge (KIND_PI = 1) or the velocity-gauge
+    operator (KIND_PI = 2) with the angular factors of PhotoIon.f90:66-83; zero unless l' = l +- 1.  The reference
+    writes MatElem_All.dat only for its Gaussian / LG-beam branches (angular integrals outside SURVEY 8); this fills
+    the same file with the plane-wave couplings so that READ_COUP consumers can run on the GPU solver's output."""
+    import numpy as np
+    nlm = len(channels)
+    z = np.zeros((nlm * n1_max, nlm * n1_max, 1), dtype=np.complex128)
+    for a_, (li, mi) in enumerate(channels):
+        for b_, (lj, mj) in enumerate(channels):
+            if abs(li - lj) != 1 or b_ < a_:
+                continue
+            # <bra = (li, mi)| A |ket = (lj, mj)>: the reference's c0, c1, c2 with l0 = lj (initial), lf = li (final)
+            l0, m0, lf, mf = lj, mj, li, mi
+            t3a = three_j(lf, 1, l0, -mf, mph, m0)
+            if kind_pi == 1:
+                t3b = three_j(lf, 1, l0, 0, 0, 0)
+                c1 = (-1.0) ** (lf + l0 + mf) * math.sqrt(float((2 * lf + 1) * (2 * l0 + 1))) * t3a * t3b
+                c0 = 1.0; coef = [c1, 0.0, 0.0]
+            else:
+                c0 = math.sqrt(float(l0 + 1)) * t3a
+                c1, c2 = (float(l0 + 1), -1.0) if lf == l0 + 1 else (float(l0), 1.0)
+                coef = [0.0, c1, c2]
+            for nj in range(1, n1_max + 1):
+                D = prob.dipole_elements(l0, nj, lf, 1, n1_max, coef)
+                z[a_ * n1_max: (a_ + 1) * n1_max, b_ * n1_max + nj - 1, 0] = c0 * D
+    return z

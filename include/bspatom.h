@@ -13,6 +13,7 @@
  */
 #ifndef BSPATOM_H
 #define BSPATOM_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -114,11 +115,22 @@ int bspatom_last_timing(const bspatom_problem *p, double ms[6]);
 /* ---- LAPACK symbol boundary ---------------------------------------------------- */
 /* Fortran-77 ABI of DSYGV as called at matrices.f90:248.  ITYPE=1, UPLO='U' or 'L'; A and B must
  * be banded with half-width <= 15 (they are, at the reference's call site); JOBZ='N' returns the
- * eigenvalues, JOBZ='V' additionally returns S-orthonormal eigenvectors by inverse iteration.
- * info = -k for a bad k-th argument, n+i if B is not positive definite. */
+ * eigenvalues, JOBZ='V' additionally returns all n B-orthonormal eigenvectors (inverse iteration,
+ * re-orthogonalised inside clusters).  LWORK >= max(1, 3n-1) or -1 (query) as for DSYGV.
+ * info = -k for a bad k-th argument (LAPACK numbering), n+i if B is not positive definite, n if the GPU
+ * path failed (message on stderr).  Trailing hidden CHARACTER lengths: size_t, as flang / gfortran pass them.
+ * libbspatom_lapack.so exports the same routine under the plain name `dsygv_` (csrc/lapack_shim.c). */
 void bsp_dsygv_(const int *itype, const char *jobz, const char *uplo, const int *n, double *a,
                 const int *lda, double *b, const int *ldb, double *w, double *work, const int *lwork,
-                int *info, int jobz_len, int uplo_len);
+                int *info, size_t jobz_len, size_t uplo_len);
+
+/* ---- run-time switches (tests, A/B comparisons) ----------------------------------------------- */
+/* The BSP_* environment variables of DESIGN.md 4.4 are read once per process; these two calls read and
+ * change the same switches afterwards, by lower-case name without the prefix ("sb2st_ring",
+ * "sb2st_version", "sb2st_force_abort", "panel_qr", "bisect" ...).  Unknown name: BSPATOM_ERR_ARG.
+ * No reference counterpart (the reference has no switches on this path). */
+int bspatom_set_option(const char *name, int value);
+int bspatom_get_option(const char *name, int *value);
 
 /* ---- stage-level entry points (parity tests, profiling; host buffers, column-major) ---------- */
 /* C[b] = alpha * op(A[b]) op(B[b]) + beta * C[b], element strides as in csrc/common.h GemmDesc. */

@@ -10,6 +10,10 @@
 #   oracle/_ref/ref_dump.x      ref_dump_driver.f90 + the same reference objects (PhotoIon.f90 with one
 #                               diagnostic WRITE shortened, see below); also writes ref_dump.bin
 #                               (module state) for the golden fixtures.
+#   oracle/_ref/Bsp_Atom_gpu.x  THE SAME reference objects as Bsp_Atom_ref.x, linked with -lbspatom_lapack in front of
+#                               the CPU LAPACK: `dsygv_` (matrices.f90:248) resolves to the GPU library, every
+#                               other BLAS symbol still to OpenBLAS -- the link-level drop-in of INTEGRATION.md 1,
+#                               built when bspatom_amd/libbspatom_lapack.so exists.
 # LAPACK/BLAS: scipy's bundled OpenBLAS (LAPACK 3.12.0) through lapack_forward.c, since the
 # reference's `-mkl` is not in this image.  No reference source is copied into the repo:
 # the two filtered translation units live in a mktemp dir that is removed on exit.
@@ -51,5 +55,14 @@ COMMON="Modules.o ReadInputs.o matrices.o PhotoIon.o WriteWF.o grid.o CubicSplin
 LINK="$OPENBLAS -Wl,-rpath,$SCIPY_LIBS -lm"
 "$FC" -o "$OUT/Bsp_Atom_ref.x" Bsp_Atom.o $COMMON $LINK
 "$FC" -o "$OUT/ref_dump.x" ref_dump_driver.o Bsp_Atom_subs.o ${COMMON/PhotoIon.o/PhotoIon_dump.o} $LINK
+# link-level drop-in: the reference's own objects against libbspatom_lapack.so (dsygv_ -> GPU).  The forwarder object
+# is compiled WITHOUT its dsygv_ (-DNO_DSYGV) so that the only definition of that symbol is the GPU library's.
+PROD=$(cd "$HERE/../../bspatom_amd" && pwd)
+if [ -f "$PROD/libbspatom_lapack.so" ]; then
+  gcc -O2 -DNO_DSYGV -c "$HERE/lapack_forward.c" -o lapack_forward_nodsygv.o
+  "$FC" -o "$OUT/Bsp_Atom_gpu.x" Bsp_Atom.o ${COMMON/lapack_forward.o/lapack_forward_nodsygv.o} \
+        -L"$PROD" -lbspatom_lapack -lbspatom -Wl,-rpath,"$PROD" $LINK
+  echo "build_ref: built $OUT/Bsp_Atom_gpu.x (dsygv_ from $PROD/libbspatom_lapack.so)"
+fi
 rm -f *.mod
 echo "build_ref: built $OUT/Bsp_Atom_ref.x and $OUT/ref_dump.x (LAPACK: $OPENBLAS)"

@@ -9,9 +9,11 @@
  */
 #include <complex.h>
 typedef double _Complex zc;
+#ifndef NO_DSYGV   /* Bsp_Atom_gpu.x takes dsygv_ from libbspatom_lapack.so instead (build_ref.sh) */
 extern void scipy_dsygv_(int*, char*, char*, int*, double*, int*, double*, int*, double*, double*, int*, int*, long, long);
 void dsygv_(int* it, char* jz, char* ul, int* n, double* a, int* lda, double* b, int* ldb, double* w, double* wk, int* lw, int* info, long l1, long l2)
 { scipy_dsygv_(it, jz, ul, n, a, lda, b, ldb, w, wk, lw, info, l1, l2); }
+#endif
 extern void scipy_dgemv_(char*, int*, int*, double*, double*, int*, double*, int*, double*, double*, int*, long);
 void dgemv_(char* t, int* m, int* n, double* al, double* a, int* lda, double* x, int* ix, double* be, double* y, int* iy, long l)
 { scipy_dgemv_(t, m, n, al, a, lda, x, ix, be, y, iy, l); }

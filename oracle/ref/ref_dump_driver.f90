@@ -37,7 +37,11 @@
 !     KIND_PI = 1, 2: PROGRAM BSP_ATOM_PI continues into TRANS_AMP (Bsp_Atom.f90:77-80).  The unmodified routine
 !     dies in a diagnostic WRITE of an unallocated array (see build_ref.sh); with that line shortened it runs, and
 !     the amplitudes T_fi(n0_fin:n1_fin, l_fin) it leaves in the module are dumped for SURVEY 8(f).2.
-!     (CROSS_SECTIONS cannot follow: it COMPUTES with the unallocated Enl(n0,l0), PhotoIon.f90:302.)
+!     CROSS_SECTIONS (Bsp_Atom.f90:88) as written reads two module variables SOLVE_SYSTEM sets for KIND_PI >= 3 only:
+!     Enl(n0,l0) (PhotoIon.f90:302, printed as E0 and used for KIND_PI >= 5 only) and the loop bound n1_max (:385, the
+!     records are written for nf <= n1_fin, :408).  This driver gives both the values the routine evidently means --
+!     Enl(:,l_ini) = E_ini, Enl(:,l_fin) = E_fin, n1_max = n1_fin -- and then calls the reference's OWN routine, so
+!     that CSs/CrossSection_Len.dat / _Vel.dat (SURVEY 8(f).2) are pinned by the reference's arithmetic and FORMAT.
       IF( KIND_PI == 1 .OR. KIND_PI == 2 ) THEN
         CALL TRANS_AMP
         OPEN(UNIT=94, FILE='ref_tfi.bin', ACCESS='STREAM', FORM='UNFORMATTED', ACTION='WRITE')
@@ -48,6 +52,13 @@
         WRITE(94) ci_fin(1:nfun,n0_fin:n1_fin)
         WRITE(94) T_fi(n0_fin:n1_fin,lmf(nlm,1))
         CLOSE(94)
+        IF( .NOT. ALLOCATED(Enl) ) ALLOCATE( Enl(nfun,0:lmax) )
+        Enl = 0.D0
+        Enl(:,l_ini) = E_ini(:)
+        Enl(:,lmf(nlm,1)) = E_fin(:)
+        n1_max = n1_fin
+        CALL EXECUTE_COMMAND_LINE('mkdir -p CSs')
+        CALL CROSS_SECTIONS
       END IF
 !     KIND_PI >= 3: the state-selection bookkeeping SOLVE_SYSTEM leaves in the module (matrices.f90:290-358):
 !     n01(l,1:3), n1_max, Emax_fin as modified, the spectra Enl and the density-of-states factors rEki, for

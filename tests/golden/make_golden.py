@@ -64,6 +64,14 @@ BIG = {
     # BASELINE configs[1] (C2) and one channel each of C4 (l=0 and l=3 via lmax), spectra only
     "c2_2048": (nml("KIND_GRID=0 ra=0.0D0 rb=400.0D0 k=9 nfun=2048", "n0_ini=1 l_ini=0 l_fin=0 Zatom=1.0D0"), False),
     "c4_4096": (nml("KIND_GRID=0 ra=0.0D0 rb=800.0D0 k=9 nfun=4096", "n0_ini=1 l_ini=0 l_fin=1 Zatom=1.0D0"), False),
+    # BASELINE configs[4] (C5) AT ITS REAL SIZE: Rogers screened Coulomb (the reference's Yukawa-type potential), n=8192, k=11,
+    # one channel; ~15 min of the reference's DSYGV.  n > 4096 takes the first panel kernel and rings of 8 in sb2st.
+    "c5_8192": (nml("KIND_GRID=0 ra=0.0D0 rb=800.0D0 k=11 nfun=8192", "n0_ini=1 l_ini=0 l_fin=0 Zatom=20.0D0 KIND_POT=1"), False),
+    # SURVEY 8(f).4 "at scale": the grid / boundary-condition / potential variants at nfun ~ 2048
+    "exp2048": (nml("KIND_GRID=1 ra=0.0D0 rb=400.0D0 k=9 nfun=2048", "n0_ini=1 l_ini=0 l_fin=1 Zatom=1.0D0"), False),
+    "explin2048": (nml("KIND_GRID=2 rmax=40.0D0 ra=0.0D0 rb=400.0D0 k=9 nfun=2048", "n0_ini=1 l_ini=0 l_fin=1 Zatom=1.0D0"), False),
+    "bc1_2048": (nml("KIND_GRID=0 ra=0.0D0 rb=400.0D0 k=9 nfun=2048 KIND_BC1=1 KIND_BC2=1", "n0_ini=1 l_ini=0 l_fin=1 Zatom=1.0D0"), False),
+    "sf2048": (nml("KIND_GRID=0 ra=0.0D0 rb=400.0D0 k=9 nfun=2048", "n0_ini=1 l_ini=0 l_fin=4 Zatom=1.0D0 KIND_POT=2"), False),
 }
 
 # dipole matrices rij that MATRIX_SVT keeps for KIND_PI = 1 (length) / 2 (velocity).  name -> (namelist, KIND_PI)
@@ -202,8 +210,13 @@ def run_amp(name, text):
         rr = open(os.path.join(tmp, "ref_rij.bin"), "rb").read()
         R = np.frombuffer(rr[8:], dtype=np.float64).reshape(2, nfun, nfun)
         sel = [l for l in p.stdout.split("\n") if ("LIMITS FOR FINAL" in l or "Initial State" in l or "Transition Amplitudes" in l)]
+        # CSs/CrossSection_Len.dat / _Vel.dat written by the reference's CROSS_SECTIONS (see ref_dump_driver.f90)
+        csname = "CrossSection_Len.dat" if kind_pi == 1 else "CrossSection_Vel.dat"
+        cstext = open(os.path.join(tmp, "CSs", csname)).read()
+        cs = np.array([[float(t) for t in ln.split()] for ln in cstext.split("\n") if ln.strip()])
         out = dict(head=np.array(h), emax_fin=emax, E_ini=E_ini, E_fin=E_fin, ci_ini=ci_ini, ci_fin=ci_fin, T_fi=T,
-                   r1=R[0].T.copy(), r2=R[1].T.copy(), lines=np.array("\n".join(sel)), namelist=np.array(open(inp).read()))
+                   r1=R[0].T.copy(), r2=R[1].T.copy(), lines=np.array("\n".join(sel)), namelist=np.array(open(inp).read()),
+                   cs_file=np.array(csname), cs_text=np.array(cstext), cs_rows=cs)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print("%-10s KIND_PI=%d (n0,l0,m0)=(%d,%d,%d) -> (lf,mf)=(%d,%d) states %d..%d  max|T| %.6g" % (
         name, kind_pi, n0_ini, l0, m0, lf, mf, n0_fin, n1_fin, np.max(np.abs(T))), flush=True)
@@ -317,7 +330,10 @@ def main():
         "flags": "-O2 (x86-64 baseline, no FMA)",
         "lapack": "scipy-bundled OpenBLAS 0.3.28 / LAPACK 3.12.0 (scipy_dsygv_), 8 threads",
     }
-    json.dump(man, open(os.path.join(HERE, "MANIFEST.json"), "w"), indent=1)
+    mpath = os.path.join(HERE, "MANIFEST.json")
+    if os.path.exists(mpath):                      # keep the notes other modes left there
+        old = json.load(open(mpath)); old.update(man); man = old
+    json.dump(man, open(mpath, "w"), indent=1)
 
 if __name__ == "__main__":
     main()

@@ -1,0 +1,32 @@
+"""bench.py through the driver's multi-GPU launch line at N = 1: `python -m torch.distributed.run --nproc-per-node 1 ...`
+initialises RCCL (backend "nccl") and sends the spectra through the all-gather of bspatom_amd/parallel.py, so the
+collective branch of the bench runs on hardware once per test session.  The file sorts first: the child process
+starts before this pytest process has touched the GPU."""
+import json
+import os
+import subprocess
+import sys
+import pytest
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_under_torchrun_one_rank(scaling):
+    port = 29600 + os.getpid() % 300 + (0 if scaling == "weak" else 1)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+           "--nfun", "1024", "--rb", "200", "--channels", "8", "--scaling", scaling, "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["scaling"] == scaling and d["unit"] == "eigensolves/s" and d["value"] > 0
+    assert d["config"]["channels_total"] == 8 and d["config"]["channels_per_gpu"] == [8]
+    assert "RCCL" in d["config"]["parallelism"]
+    assert d["rydberg_max_rel_err_n<=8"] < 1e-9
+    r = d["roofline"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernels"][0]["kernel"].startswith("sb2st")

@@ -18,24 +18,43 @@ def figures(E, Eref):
     return np.max(np.abs(E - Eref) / np.abs(Eref)), np.max(np.abs(E - Eref)) / lam
 
 
-def full_size_bar(E, Eref, tag):
-    """Linear-grid parity bar:  |dE| <= 1e-10 |E| + 1/2 eps lambda_max  for EVERY eigenvalue, i.e. 1e-10 relative
-    (north_star) except where that would be finer than half an ulp of the matrix norm (eigenvalues within
-    ~2e-3 of zero at lambda_max ~ 1.5e3).  There the reference's own LAPACK rounding is 1e-13..3e-13 absolute
-    (measured against the exact Rydberg values), so no solver can reproduce it to 1e-10 relative.
-    Also: normwise 1e-13, and the exceptions to the pure relative bar are counted and must all be such
-    near-zero eigenvalues."""
-    eps = np.finfo(float).eps
+def load_truth(name):
+    """113-bit truth of selected eigenvalues per channel (tests/golden/make_truth.py): {l: (idx, truth)}."""
+    t = load_golden("truth_" + name)
+    return {int(l): (t["idx"][t["chan"] == l], t["hi"][t["chan"] == l]) for l in np.unique(t["chan"])}
+
+
+def full_size_bar(E, Eref, tag, truth=None):
+    """Linear-grid parity bar (north_star: every eigenvalue within 1e-10 relative of reference DSYGV).
+      (1) normwise |dE| <= 1e-13 lambda_max, every eigenvalue;
+      (2) |dE| <= 1e-10 |E_ref| for every eigenvalue, EXCEPT where the reference's own LAPACK value is not determined
+          to that accuracy: such an exception must be one of the eigenvalues whose 113-bit truth is stored (the ones
+          nearest zero), and there the GPU value must be as close to the truth as the reference's own noise level
+          in that channel allows:  |E_gpu - truth| <= 1e-10 |E| + 2 max_{near zero} |E_ref - truth|.
+      (3) measured against the TRUTH, the GPU spectrum misses 1e-10 relative at no more eigenvalues than the
+          reference's does (+1: two LAPACK drivers differ by one on these pencils)."""
     lam = np.max(np.abs(Eref))
     d = np.abs(E - Eref)
     rel = d / np.abs(Eref)
-    exc = rel > 1e-10
-    note("%s: worst rel %.2e at E=%.2e (|dE| %.1e = %.2f eps*lam_max)  normwise %.2e  exceptions to pure 1e-10 relative: %d"
-         % (tag, np.max(rel), Eref[np.argmax(rel)], d[np.argmax(rel)], d[np.argmax(rel)] / (eps * lam), np.max(d) / lam,
-            int(np.sum(exc))))
-    assert np.all(d <= 1e-10 * np.abs(Eref) + 0.5 * eps * lam)
-    assert np.max(d) / lam <= 1e-13
-    assert np.all(np.abs(Eref[exc]) < 0.5 * eps * lam / 1e-10)
+    exc = np.where(rel > 1e-10)[0]
+    msg = "%s: worst rel %.2e at E=%.2e  normwise %.2e  exceptions to 1e-10 relative vs reference: %d" % (
+        tag, np.max(rel), Eref[np.argmax(rel)], np.max(d) / lam, len(exc))
+    assert np.max(d) / lam <= 1e-13, msg
+    if truth is None:
+        note(msg)
+        assert len(exc) == 0, msg
+        return
+    idx, tru = truth
+    eg = np.abs(E[idx] - tru); er = np.abs(Eref[idx] - tru)
+    near = np.argsort(np.abs(tru))[:24]
+    noise = np.max(er[near])
+    ng = int(np.sum(eg > 1e-10 * np.abs(tru))); nr = int(np.sum(er > 1e-10 * np.abs(tru)))
+    note(msg + " | vs truth: gpu worst rel %.2e (%d beyond 1e-10), reference worst rel %.2e (%d beyond 1e-10), "
+         "near-zero abs error gpu %.2e reference %.2e" % (np.max(eg / np.abs(tru)), ng, np.max(er / np.abs(tru)), nr,
+                                                         np.max(eg[near]), noise))
+    assert set(exc) <= set(idx), msg + ": exception at an eigenvalue that is not next to zero: %s" % exc
+    assert np.all(eg <= 1e-10 * np.abs(tru) + 2.0 * np.maximum(er, noise)), msg
+    assert ng <= nr + 1, msg
 
 
 @pytest.mark.parametrize("name", SMALL_CASES + ["lin1024", "c2_2048", "c3_1024_l31", "c5_1024_k11"])
@@ -47,14 +66,13 @@ def test_spectra_vs_reference(name):
     E, info = prob.solve(0, lmax + 1)
     assert np.all(info == 0)
     lin = inp.kind_grid == 0
+    truth = load_truth(name) if os.path.exists(os.path.join(ROOT, "tests", "golden", "truth_%s.npz" % name)) else {}
     for l in range(lmax + 1):
         rel, nrm = figures(E[l], g["E"][l])
         note("solve %s l=%d n=%d: rel %.2e normwise %.2e  timing %s" % (name, l, prob.nfun, rel, nrm, prob.last_timing()))
         assert nrm <= 1e-13
         if lin:
-            # relative 1e-10 wherever |E| >= 1e-3; eigenvalues nearer to zero are compared with the mixed bound
-            # (the reference's own rounding is ~1e-13 absolute there, see full_size_bar)
-            full_size_bar(E[l], g["E"][l], "  bar %s l=%d" % (name, l))
+            full_size_bar(E[l], g["E"][l], "  bar %s l=%d" % (name, l), truth.get(l))
     prob.close()
 
 
@@ -209,8 +227,9 @@ def test_c4_channels_at_full_size():
     prob = capi.Problem(input_from_case("c4_4096"))
     E, info = prob.solve(0, 2)
     assert np.all(info == 0)
+    truth = load_truth("c4_4096")
     for l in range(2):
-        full_size_bar(E[l], g["E"][l], "solve c4_4096 l=%d" % l)
+        full_size_bar(E[l], g["E"][l], "solve c4_4096 l=%d" % l, truth[l])
         # truth check: the GPU spectrum is at least as close to the exact Rydberg values as the reference's
         nq = np.arange(1, 11) + l
         exact = -0.5 / nq ** 2
@@ -231,8 +250,9 @@ def test_full_size_properties_128_channels():
         nq = np.arange(l + 1, l + 5)
         assert np.max(np.abs(E[l, :4] + 0.5 / nq ** 2) * 2 * nq ** 2) < 1e-9
     assert np.all(np.diff(E[:, 0]) > 0)
+    truth = load_truth("c4_4096")
     for l in range(2):
-        full_size_bar(E[l], g["E"][l], "batch128 c4_4096 l=%d" % l)
+        full_size_bar(E[l], g["E"][l], "batch128 c4_4096 l=%d" % l, truth[l])
     prob.close()
 
 
@@ -409,3 +429,298 @@ def test_transition_amplitudes_vs_reference(name):
     assert err <= (3e-7 if "KIND_GRID=1" in str(g["namelist"]) else 1e-10), err
     for line in r["stdout"].split("\n"):
         assert line in [x.strip() for x in str(g["lines"]).split("\n")], line
+
+
+# ---- round 2: the paths no test executed before (configs_untested, weak 2/8, missing 3-5) -----------------
+class _Options:
+    """Flip run-time switches of the library for one test and restore them."""
+    def __init__(self, **kw):
+        self.kw = kw
+    def __enter__(self):
+        self.old = {k: capi.get_option(k) for k in self.kw}
+        for k, v in self.kw.items():
+            capi.set_option(k, v)
+        return self
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            capi.set_option(k, v)
+
+
+def test_c5_at_full_size():
+    """BASELINE configs[4] AT ITS REAL SIZE: Rogers screened Coulomb (KIND_POT=1, Zatom=20), N_bsp=8192, k=11, one
+    channel, against the compiled reference's spectrum (tests/golden/c5_8192.npz, ~15 min of LAPACK DSYGV in the build
+    container) and against the 113-bit truth of the eigenvalues nearest zero.  n > 4096 takes the first panel
+    kernel for the tall panels (sy2sb.hip: launch_pq), rings of 8 workgroups in the bulge chasing and the
+    four-eigenvalues-per-thread bisection (146 KB of LDS)."""
+    g = load_golden("c5_8192")
+    prob = capi.Problem(input_from_case("c5_8192"))
+    assert prob.nfun == 8192 and prob.k == 11
+    E, info = prob.solve(0, 1)
+    assert np.all(info == 0)
+    note("c5_8192 timing %s" % prob.last_timing())
+    full_size_bar(E[0], g["E"][0], "solve c5_8192 l=0", load_truth("c5_8192")[0])
+    prob.close()
+
+
+@pytest.mark.parametrize("name", ["bc1_2048", "sf2048", "exp2048", "explin2048"])
+def test_variants_at_scale(name):
+    """SURVEY 8(f).4 at scale (nfun ~ 2048): KIND_BC=1 (first/last B-spline kept, ReadInputs.f90:42-45), the Simons-Fues
+    l-dependent Bl/r^2 term (KIND_POT=2, matrices.f90:151; l = 0..4 so that Bl(l>3) = 0 is exercised), and the
+    exponential / exponential-linear knot sequences (grid.f90:35-61; explin resizes nfun to 2456).  Linear grids: the
+    1e-10 relative bar of full_size_bar.  Grids with an exponential part: normwise 1e-13 against the reference (two
+    LAPACK runs differ by 2e-8..3e-7 RELATIVE at the eigenvalues next to zero there) plus the truth bar:
+    the GPU value of every stored eigenvalue is as close to the 113-bit truth as the reference's noise allows."""
+    g = load_golden(name)
+    inp = input_from_case(name)
+    prob = capi.Problem(inp)
+    nch = g["E"].shape[0]
+    assert prob.nfun == g["E"].shape[1]
+    E, info = prob.solve(0, nch)
+    assert np.all(info == 0)
+    truth = load_truth(name)
+    for l in range(nch):
+        tag = "solve %s l=%d n=%d" % (name, l, prob.nfun)
+        if inp.kind_grid == 0:
+            full_size_bar(E[l], g["E"][l], tag, truth[l])
+        else:
+            lam = np.max(np.abs(g["E"][l]))
+            idx, tru = truth[l]
+            eg = np.abs(E[l][idx] - tru); er = np.abs(g["E"][l][idx] - tru)
+            near = np.argsort(np.abs(tru))[:24]
+            note("%s: normwise vs reference %.2e | vs truth: gpu worst rel %.2e abs %.2e (%.2f eps lam), reference worst rel %.2e abs %.2e (%.2f eps lam)"
+                 % (tag, np.max(np.abs(E[l] - g["E"][l])) / lam, np.max(eg / np.abs(tru)), eg.max(), eg.max() / (np.finfo(float).eps * lam),
+                    np.max(er / np.abs(tru)), er.max(), er.max() / (np.finfo(float).eps * lam)))
+            assert np.max(np.abs(E[l] - g["E"][l])) <= 1e-13 * lam
+            assert np.all(eg <= 1e-10 * np.abs(tru) + 2.0 * np.maximum(er, np.max(er[near])))
+    prob.close()
+
+
+def test_sb2st_fallback_paths():
+    """Every branch of the bulge-chasing launch against the default (rings by channel count), on 12 channels at
+    n = 1024 (spectra must agree BIT FOR BIT with the ring paths: the arithmetic and its order do not depend on who
+    runs a sweep; the one-sweep-per-workgroup generation v3 is an independent implementation and agrees to rounding):
+      ring of 8, ring of 4, ring of 2, one workgroup per channel (version 7),
+      a forced ABORT of the handshake (member 0 runs the channel alone, the time-out branch),
+      members 'on different XCDs' (same fallback through the other branch),
+      version 3."""
+    inp = input_from_case("c3_1024_l31")
+    prob = capi.Problem(inp)
+    E0, info = prob.solve(0, 12)
+    assert np.all(info == 0)
+    lam = np.max(np.abs(E0))
+    for kw in [dict(sb2st_ring=8), dict(sb2st_ring=4), dict(sb2st_ring=2), dict(sb2st_version=7),
+               dict(sb2st_force_abort=1), dict(sb2st_force_abort=2), dict(sb2st_ring=8, sb2st_force_abort=1)]:
+        with _Options(**kw):
+            E, info = prob.solve(0, 12)
+        assert np.all(info == 0), kw
+        assert np.array_equal(E, E0), (kw, np.max(np.abs(E - E0)) / lam)
+    with _Options(sb2st_version=3):
+        E, info = prob.solve(0, 12)
+    assert np.all(info == 0)
+    note("sb2st version 3 vs default: normwise %.2e" % (np.max(np.abs(E - E0)) / lam))
+    assert np.max(np.abs(E - E0)) <= 1e-13 * lam
+    prob.close()
+
+
+def test_panel_qr_first_kernel_matches_second():
+    """panel_qr_kernel (the first panel kernel) serves every panel above 4096 rows; forced for ALL panels at n = 2048
+    it must reproduce the spectra of the LDS-DMA kernel to rounding (they order the reductions differently)."""
+    prob = capi.Problem(input_from_case("c2_2048"))
+    E0, info = prob.solve(0, 1)
+    with _Options(panel_qr=1):
+        E, info = prob.solve(0, 1)
+    assert np.all(info == 0)
+    lam = np.max(np.abs(E0))
+    note("panel_qr 1 vs 2 at n=2048: normwise %.2e" % (np.max(np.abs(E - E0)) / lam))
+    assert np.max(np.abs(E - E0)) <= 2e-14 * lam
+    g = load_golden("c2_2048")
+    full_size_bar(E[0], g["E"][0], "panel_qr=1 c2_2048", load_truth("c2_2048")[0])
+    prob.close()
+
+
+def test_unknown_option_is_rejected():
+    with pytest.raises(capi.BspAtomError):
+        capi.set_option("no_such_switch", 1)
+    assert capi.get_option("sb2st_version") == 8
+
+
+def test_state_is_invalidated_by_assemble():
+    """bspatom_assemble overwrites the bands of the last solve: eigvec afterwards must refuse, not use stale data."""
+    prob = capi.Problem(input_from_case("c1_lin"))
+    prob.solve(0, 2)
+    prob.eigvec(0, 1)
+    prob.assemble(1, 1)
+    with pytest.raises(capi.BspAtomError):
+        prob.eigvec(0, 1)
+    prob.close()
+
+
+def test_bsp_dsygv_all_vectors_at_2048():
+    """DSYGV(1,'V','U') contract at scale (matrices.f90:248): ALL nfun vectors, Z^T S Z = I, residual, on the C2 pencil
+    (n = 2048, oracle-assembled bands = the reference's, bit for bit)."""
+    import oracle as orc
+    from tests_truth import case_cfg
+    c = case_cfg("c2_2048")
+    rt, aind, xg, wg = orc.grid(c)
+    SB, HB = orc.assemble_bands(c, rt, aind, xg, wg, 0, 1)
+    S = orc.band_to_dense_upper(SB); H = orc.band_to_dense_upper(HB[0])
+    w, Z, U, info = capi.dsygv(H, S, jobz="V", uplo="U")
+    assert info == 0
+    g = load_golden("c2_2048")
+    full_size_bar(w, g["E"][0], "bsp_dsygv_('V') c2_2048", load_truth("c2_2048")[0])
+    Sf = S + np.triu(S, 1).T; Hf = H + np.triu(H, 1).T
+    SZ = Sf @ Z
+    orth = np.max(np.abs(Z.T @ SZ - np.eye(c.nfun)))
+    resid = np.max(np.abs(Hf @ Z - SZ * w)) / np.max(np.abs(w))
+    note("bsp_dsygv_('V') n=2048: Z^T S Z - I %.2e  residual/lambda_max %.2e" % (orth, resid))
+    assert orth <= 1e-8 and resid <= 1e-11
+    assert np.max(np.abs(np.triu(U).T @ np.triu(U) - Sf)) < 1e-12
+
+
+def test_bsp_dsygv_argument_checks():
+    """LAPACK's argument numbering: LWORK too small -> -11; the query returns 3n-1."""
+    import ctypes as C
+    n = 8
+    a = np.eye(n, order="F"); b = np.eye(n, order="F"); w = np.zeros(n); work = np.zeros(64)
+    def call(lwork, jobz=b"N"):
+        it = C.c_int(1); nn = C.c_int(n); ld = C.c_int(n); lw = C.c_int(lwork); info = C.c_int(7)
+        capi.lib().bsp_dsygv_(C.byref(it), C.c_char_p(jobz), C.c_char_p(b"U"), C.byref(nn), capi._p(a), C.byref(ld), capi._p(b),
+                              C.byref(ld), capi._p(w), capi._p(work), C.byref(lw), C.byref(info), C.c_size_t(1), C.c_size_t(1))
+        return info.value
+    assert call(3 * n - 2) == -11
+    assert call(-1) == 0 and work[0] == 3 * n - 1
+    assert call(3 * n - 1, b"X") == -2
+    assert call(3 * n - 1) == 0 and np.allclose(w, 1.0)
+
+
+@pytest.mark.parametrize("name", ["bsp0", "c1_lin"])
+def test_reference_binary_on_gpu_dsygv(tmp_path, name):
+    """THE REFERENCE'S OWN PROGRAM with `dsygv_` resolved to the GPU library: oracle/_ref/Bsp_Atom_gpu.x is the compiled,
+    unmodified reference (oracle/ref/build_ref.sh) linked with -lbspatom_lapack in front of the CPU LAPACK
+    (INTEGRATION.md 1).  Its Enl.dat and wf_n0.dat against the fixtures of the all-CPU reference build."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "Bsp_Atom_gpu.x")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/Bsp_Atom_gpu.x not built (needs /root/reference in the build container)")
+    g = load_golden(name)
+    with open(golden_input(name)) as fin:
+        p = subprocess.run([exe], stdin=fin, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "Program Finished!" in p.stdout
+    nch, nfun = g["E"].shape
+    E = _read_enl(tmp_path / "Enl.dat", nfun, nch)
+    lam = np.max(np.abs(g["E"]))
+    note("reference binary + GPU dsygv_ %s: Enl.dat normwise %.2e" % (name, np.max(np.abs(E - g["E"])) / lam))
+    assert np.max(np.abs(E - g["E"])) / lam < 1e-13
+    wf = np.loadtxt(tmp_path / "wf_n0.dat")
+    rows = g["wf_rows"]; idx = g["wf_idx"]
+    sgn = np.sign(np.dot(wf[idx, 1], rows[:, 1]))
+    assert np.max(np.abs(sgn * wf[idx, 1] - rows[:, 1])) <= 2e-8 * np.max(np.abs(rows[:, 1]))
+    # the whole stdout, line by line, except the numbers DSYGV produced (compared above) and the sign of the vector
+    ref_lines = [l for l in str(g["stdout"]).split("\n") if not l.startswith("REF_TIME_")]
+    assert len(p.stdout.split("\n")) >= len(ref_lines) - 4
+
+
+# ---- SURVEY 8(f).2 / (f).3: cross-section files of KIND_PI = 1, 2 and the MatElem_All.dat hand-off ------------------
+@pytest.mark.parametrize("name", ["ta_len_s", "ta_vel_s", "ta_len_p", "ta_vel_p"])
+def test_cross_section_file_vs_reference(tmp_path, name):
+    """CSs/CrossSection_Len.dat / _Vel.dat against the file the reference's own CROSS_SECTIONS wrote (fixture: the dump
+    driver sets the two module variables that routine reads but SOLVE_SYSTEM leaves unset for KIND_PI = 1, 2, see
+    oracle/ref/ref_dump_driver.f90).  Same number of records, same FORMAT(2G20.10E3) layout, E_fin to the file's 10
+    digits, sigma to 1e-9 of its maximum (T_fi agrees to 1e-13..8e-13 of max|T| on linear grids and enters squared;
+    3e-7 on the grid with an exponential part, as for T_fi itself)."""
+    from bspatom_amd import host
+    g = load_golden(name)
+    if "cs_rows" not in g.files:
+        pytest.skip("fixture predates the cross-section dump")
+    r = host.cross_sections(str(g["namelist"]), outdir=str(tmp_path))
+    assert os.path.basename(r["file"]) == str(g["cs_file"])
+    mine = open(tmp_path / r["file"]).read().split("\n")
+    ref = str(g["cs_text"]).split("\n")
+    assert len(mine) == len(ref)
+    assert all(len(a) == len(b) for a, b in zip(mine, ref))
+    R = g["cs_rows"]; M = np.array(r["rows"])
+    assert M.shape == R.shape
+    tol = 3e-7 if "KIND_GRID=1" in str(g["namelist"]) else 1e-9
+    assert np.max(np.abs(M[:, 0] - R[:, 0])) <= 2e-10 * np.max(np.abs(R[:, 0])) + tol * 1e-3
+    err = np.max(np.abs(M[:, 1] - R[:, 1])) / np.max(np.abs(R[:, 1]))
+    note("cross sections %s: %d records, max|sigma| %.4g Mb, err %.2e" % (name, len(R), np.max(R[:, 1]), err))
+    assert err <= tol
+    # the Python host's full run (spectra files + TRANS_AMP + CROSS_SECTIONS + 'Program Finished!')
+    E, c, text = host.run(str(g["namelist"]), outdir=str(tmp_path))
+    assert "Program Finished!" in text and "Calculating Cross Sections" in text
+    assert os.path.exists(tmp_path / "Enl.dat") and os.path.exists(tmp_path / "CSs" / str(g["cs_file"]))
+
+
+@pytest.mark.parametrize("name", ["ta_len_s", "ta_vel_p"])
+def test_fortran_host_cross_sections(tmp_path, name):
+    """bsp_atom_host.x with KIND_PI = 1, 2: creates CSs/ itself (Bsp_Atom.f90:59-60), writes the cross-section file with
+    flang's own FORMAT(2G20.10E3) -- as the reference build does -- and ends with 'Program Finished!'."""
+    import subprocess
+    exe = os.path.join(ROOT, "bspatom_amd", "bsp_atom_host.x")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran host not built (no flang)")
+    g = load_golden(name)
+    if "cs_rows" not in g.files:
+        pytest.skip("fixture predates the cross-section dump")
+    with open(golden_input(name)) as fin:
+        p = subprocess.run([exe], stdin=fin, cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "Program Finished!" in p.stdout
+    for line in str(g["lines"]).split("\n"):
+        assert line.rstrip() in [x.rstrip() for x in p.stdout.split("\n")], line
+    mine = open(tmp_path / "CSs" / str(g["cs_file"])).read().split("\n")
+    ref = str(g["cs_text"]).split("\n")
+    assert len(mine) == len(ref) and all(len(a) == len(b) for a, b in zip(mine, ref))
+    M = np.array([[float(t) for t in l.split()] for l in mine if l.strip()]); R = g["cs_rows"]
+    tol = 3e-7 if "KIND_GRID=1" in str(g["namelist"]) else 1e-9
+    assert np.max(np.abs(M[:, 1] - R[:, 1])) <= tol * np.max(np.abs(R[:, 1]))
+    assert np.max(np.abs(M[:, 0] - R[:, 0])) <= 2e-10 * np.max(np.abs(R[:, 0])) + tol * 1e-3
+
+
+def test_fortran_host_creates_css_directory(tmp_path):
+    """`mkdir CSs` at start-up for every KIND_PI (Bsp_Atom.f90:59-60), and the full stdout header of a KIND_PI = 0 run."""
+    import subprocess
+    exe = os.path.join(ROOT, "bspatom_amd", "bsp_atom_host.x")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran host not built (no flang)")
+    g = load_golden("c1_lin")
+    with open(golden_input("c1_lin")) as fin:
+        p = subprocess.run([exe], stdin=fin, cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0
+    assert os.path.isdir(tmp_path / "CSs")
+    # header lines of MATRIX_SVT / SOLVE_SYSTEM (matrices.f90:52,194,256-259), in the reference's order
+    ref = [l.rstrip() for l in str(g["stdout"]).split("\n")]
+    mine = [l.rstrip() for l in p.stdout.split("\n")]
+    for key in ("Calculating S, V, U and T Matrices", "Matrices Calculated", "HC = ESC eigenvalue solved", "Writing down Initial State WF",
+                "Number of Knot Points:", "Multiplicity of END points:"):
+        a = [l for l in ref if key in l]; b = [l for l in mine if key in l]
+        assert a == b, key
+    pos = [next(i for i, l in enumerate(mine) if k in l) for k in ("Calculating S, V, U and T", "Matrices Calculated", "l0 =  0")]
+    assert pos == sorted(pos)
+
+
+def test_dipole_matelem_file(tmp_path):
+    """The plane-wave couplings in the MatElem_All.dat layout (host.dipole_matelem, write_matelem_all): the s -> p block
+    equals the dipole elements TRANS_AMP uses (same C-ABI call), the file reads back the way READ_COUP reads it."""
+    from bspatom_amd import host
+    inp = input_from_case("c1_lin")
+    prob = capi.Problem(inp)
+    prob.solve(0, prob.lmax + 1)
+    n1 = 5
+    z = host.dipole_matelem(prob, [(0, 0), (1, 0)], n1, kind_pi=1)
+    assert z.shape == (2 * n1, 2 * n1, 1)
+    t3 = host.three_j(1, 1, 0, 0, 0, 0)
+    c1 = (-1.0) ** 1 * np.sqrt(3.0) * t3 * t3
+    for nj in range(1, n1 + 1):
+        D = prob.dipole_elements(0, nj, 1, 1, n1, [c1, 0.0, 0.0])
+        # <c(1,n)| c1 r |c(0,nj)> = <c(0,nj)| c1 r |c(1,n)>: the upper-triangle block holds the transposed pairs
+        assert np.allclose(z[nj - 1, n1:2 * n1, 0].real, D, rtol=0, atol=1e-11 * np.max(np.abs(D)))
+    assert np.all(z[:n1, :n1] == 0) and np.all(z[n1:, n1:] == 0)       # no l -> l couplings
+    assert np.max(np.abs(z[:n1, n1:])) > 0.1
+    path = tmp_path / "MatElem_All.dat"
+    host.write_matelem_all(str(path), n1, z)
+    n1r, back = host.read_matelem_all(str(path), 1)
+    iu = np.triu_indices(2 * n1)
+    assert n1r == n1 and np.allclose(back[iu], z[iu], rtol=1e-9, atol=1e-300)
+    prob.close()

@@ -196,8 +196,8 @@ def test_bisect(n, batch):
 def test_bisect_edge_cases():
     """The shapes the counting kernel special-cases: n = 1, 2, 33 (padding to 32-row history words), the zero matrix,
     a multiple eigenvalue (every bracket of the first-level grid search lands in the same cell), a split matrix with
-    exact zeros on the off-diagonal, eigenvalues 1e-12 of the norm next to zero (the absolute floor eps/16 |T| of
-    the stopping rule applies: error <= eps |T|), and a graded matrix spanning 12 decades."""
+    exact zeros on the off-diagonal, eigenvalues 1e-12 of the norm next to zero, and a graded matrix spanning 12 decades
+    (normwise bar here; the relative accuracy of the graded case is test_bisect_relative_accuracy_vs_truth)."""
     from scipy.linalg import eigvalsh_tridiagonal
     rng = np.random.default_rng(7)
     cases = []
@@ -223,6 +223,30 @@ def test_bisect_edge_cases():
             note("bisect edge %s err %.2e" % (name, err))
             assert np.all(np.diff(w[b]) >= 0), name
             assert err <= 8 * np.finfo(float).eps * max(1, np.sqrt(n)), (name, err)
+
+
+@pytest.mark.parametrize("n,batch", [(97, 1), (1000, 3), (4096, 2), (8192, 1)])
+def test_bisect_relative_accuracy_vs_truth(n, batch):
+    """Stopping rule of the batched bisection: RELATIVE (2 eps |x|), nothing absolute.  Scaled-diagonally-dominant graded
+    matrices determine every eigenvalue to high relative accuracy, so a Sturm bisection in doubles must deliver
+    them to a few ulps whatever their size.  Truth: 113-bit bisection on the same (d, e) (oracle/truth_quad.c).  The
+    eigenvalues span 14 decades (|x| down to 1e-14 |T|: up to 45 levels more than the bulk, all in the multisection
+    tail of the kernel), both signs; n = 8192 takes the four-per-thread instance.  Bar: 64 eps relative, every one."""
+    from oracle import truth as qt
+    rng = np.random.default_rng(n + batch)
+    d = np.zeros((batch, n)); e = np.zeros((batch, n - 1))
+    for b in range(batch):
+        mag = 10.0 ** rng.uniform(-14, 0, n) * (10.0 ** b)
+        mag[rng.integers(0, n, 5)] = 1.0 * (10.0 ** b)                      # some at the norm itself
+        d[b] = mag * rng.choice([-1.0, 1.0], n)
+        e[b] = 1e-3 * np.sqrt(np.abs(d[b, :-1] * d[b, 1:])) * rng.choice([-1.0, 1.0], n - 1)
+    w = capi.stage_bisect(d, e)
+    for b in range(batch):
+        assert np.all(np.diff(w[b]) >= 0)
+        tru = qt.tridiag_eigs(d[b], e[b], w[b])
+        rel = np.abs(w[b] - tru) / np.abs(tru)
+        note("bisect vs truth n %d b%d: worst relative %.2e (%.1f eps) at x=%.2e" % (n, b, rel.max(), rel.max() / np.finfo(float).eps, tru[np.argmax(rel)]))
+        assert rel.max() <= 64 * np.finfo(float).eps
 
 
 # ---- SURVEY 8(f).2: dipole matrices accumulated in MATRIX_SVT's quadrature loop -----------------------------

@@ -287,3 +287,35 @@ def test_committed_bench_line_keeps_the_contract():
     assert abs(d["value"] - d["config"]["channels_per_gpu"] * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_matelem_all_round_trip(tmp_path):
+    """CSs/MatElem_All.dat (PhotoIon.f90:255-266 writer, ReadInputs.f90:324-366 reader): header `n1_max nbra nket`, records
+    FORMAT(2I8,X,20G20.10) for jket >= ibra; READ_COUP reads them list-directed, 2 nfields reals per record."""
+    from bspatom_amd import host
+    rng = np.random.default_rng(5)
+    for ncomp in (1, 2, 5):
+        z = rng.standard_normal((6, 6, ncomp)) + 1j * rng.standard_normal((6, 6, ncomp))
+        z[2, 3, 0] = 0.0
+        z[1, 4, 0] = 1.2345678901e-7 - 9.87e12j
+        path = tmp_path / ("MatElem_All_%d.dat" % ncomp)
+        host.write_matelem_all(str(path), 3, z)
+        lines = open(path).read().split("\n")
+        assert lines[0].split() == ["3", "6", "6"]
+        assert len(lines[1]) == 17 + 40 * ncomp and lines[1][:17] == "       1       1 "
+        assert len([l for l in lines[1:] if l]) == 6 * 7 // 2
+        n1, back = host.read_matelem_all(str(path), nfields=ncomp)
+        assert n1 == 3
+        iu = np.triu_indices(6)
+        assert np.allclose(back[iu], z[iu], rtol=1e-9, atol=0)
+        assert not np.any(back[np.tril_indices(6, -1)])
+
+
+def test_fortran_g_with_exponent_width():
+    """G20.10E3 (CROSS_SECTIONS, FORMAT 400): F editing leaves e + 2 = 5 blanks, E editing has three exponent digits."""
+    from bspatom_amd.host import fortran_g
+    assert fortran_g(1.0, 20, 10, 3) == "    1.000000000     "
+    assert fortran_g(1.5e-5, 20, 10, 3) == "   0.1500000000E-004"
+    assert fortran_g(-2.5e12, 20, 10, 3) == "  -0.2500000000E+013"
+    assert fortran_g(0.0, 20, 10, 3) == "    0.000000000     "
+    assert fortran_g(0.25, 20, 10) == "    0.2500000000    "

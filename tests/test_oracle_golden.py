@@ -180,3 +180,46 @@ def test_three_j_known_values():
     for j3 in (1, 2, 3):
         s = sum(orc.three_j(2, 1, j3, m1, m2, -m1 - m2) ** 2 for m1 in range(-2, 3) for m2 in (-1, 0, 1) if abs(m1 + m2) <= j3)
         assert abs(s - 1.0) < 1e-13
+
+
+# ---- 113-bit truth fixtures (tests/golden/make_truth.py) ---------------------------------------------------------
+@pytest.mark.parametrize("name", ["c1_lin", "lin256"])
+def test_truth_fixture_reproduces_and_brackets_the_reference(name):
+    """The committed truth values are what oracle/truth_quad.c computes from the oracle's bands (bit for bit: the
+    computation is deterministic), every one lies within LAPACK's normwise error of the reference's value, and a
+    dense double-precision solve of the same pencil (scipy eigh, another LAPACK driver) agrees to 1e-13 normwise."""
+    import scipy.linalg as sla
+    from oracle import truth as qt
+    from tests_truth import case_cfg
+    t = load_golden("truth_" + name); g = load_golden(name)
+    c = case_cfg(name)
+    rt, aind, xg, wg = orc.grid(c)
+    nch = g["E"].shape[0]
+    SB, HB = orc.assemble_bands(c, rt, aind, xg, wg, 0, nch)
+    for l in (0, nch - 1):
+        sel = t["chan"] == l
+        idx = t["idx"][sel]
+        lam = float(np.max(np.abs(g["E"][l])))
+        hi, lo = qt.band_eigs(SB, HB[l], idx, g["E"][l][idx], lam)
+        assert np.array_equal(hi, t["hi"][sel]) and np.array_equal(lo, t["lo"][sel])
+        assert np.max(np.abs(g["E"][l][idx] - hi)) <= 1e-13 * lam
+        S = orc.band_to_dense_upper(SB); S = S + np.triu(S, 1).T
+        H = orc.band_to_dense_upper(HB[l]); H = H + np.triu(H, 1).T
+        w = sla.eigh(H, S, eigvals_only=True)
+        assert np.max(np.abs(w[idx] - hi)) <= 1e-13 * lam
+
+
+def test_truth_count_is_an_inertia():
+    """orc_truth_count at a point between two well-separated eigenvalues returns the index of the upper one."""
+    from oracle import truth as qt
+    from tests_truth import case_cfg
+    g = load_golden("c1_lin")
+    c = case_cfg("c1_lin")
+    rt, aind, xg, wg = orc.grid(c)
+    SB, HB = orc.assemble_bands(c, rt, aind, xg, wg, 0, 1)
+    E = g["E"][0]
+    for m in (1, 5, 30, 63):
+        x = 0.5 * (E[m - 1] + E[m])
+        cnt = qt.lib().orc_truth_count(SB.shape[1], SB.shape[0], qt._p(np.ascontiguousarray(SB)),
+                                       qt._p(np.ascontiguousarray(HB[0])), float(x), 0.0)
+        assert cnt == m
