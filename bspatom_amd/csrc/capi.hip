@@ -54,7 +54,8 @@ const OptName OPT_TABLE[] = {
     {"sy2sb_groups", "BSP_SY2SB_GROUPS", &Options::sy2sb_groups}, {"sy2sb_lookahead", "BSP_SY2SB_LOOKAHEAD", &Options::sy2sb_lookahead},
     {"sy2sb_segs", "BSP_SY2SB_SEGS", &Options::sy2sb_segs}, {"panel_qr", "BSP_PANEL_QR", &Options::panel_qr},
     {"gemm_diag", "BSP_GEMM_DIAG", &Options::gemm_diag}, {"bisect", "BSP_BISECT", &Options::bisect},
-    {"bisect_ept", "BSP_BISECT_EPT", &Options::bisect_ept}, {"no_eigvec_prefetch", "BSP_NO_EIGVEC_PREFETCH", &Options::no_eigvec_prefetch},
+    {"bisect_ept", "BSP_BISECT_EPT", &Options::bisect_ept},
+    {"bisect_tail", "BSP_BISECT_TAIL", &Options::bisect_tail}, {"no_eigvec_prefetch", "BSP_NO_EIGVEC_PREFETCH", &Options::no_eigvec_prefetch},
 };
 }  // namespace
 

@@ -47,6 +47,7 @@ struct Options {
     int panel_qr = 2;            // BSP_PANEL_QR: 1 = first panel kernel for every panel (it always serves panels above 4096 rows)
     int gemm_diag = 0;
     int bisect = 3, bisect_ept = 0;
+    int bisect_tail = 1;         // BSP_BISECT_TAIL: 0 = lock-step bisection to the end (no multisection tail), for A/B timing
     int no_eigvec_prefetch = 0;
 };
 Options &opts();

@@ -330,7 +330,7 @@ static size_t bisect3_lds_bytes(int n, int ept)
 
 template <int EPT>
 __global__ __launch_bounds__(256) void bisect3_kernel(int n, int ldn, const double *__restrict__ dall,
-                                                     const double *__restrict__ eall, double *wall, long ldw)
+                                                     const double *__restrict__ eall, double *wall, long ldw, int tail)
 {
     extern __shared__ double2 sde[];
     constexpr int NG = 256 * EPT;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void bisect3_kernel(int n, int ldn, const doub
             done[c] = (mbase + 256 * c >= n) || bracket_final(lo[c], hi[c]);
             nun += done[c] ? 0 : 1;
         }
-        if (!__syncthreads_or(nun > EPT / 2)) break;
+        if (!__syncthreads_or(nun > (tail ? EPT / 2 : 0))) break;
         int cnt[EPT];
         sturm_counts3<EPT>(de, np, mid, cnt);
 #pragma unroll
@@ -696,8 +696,8 @@ int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_
     const dim3 grid((n + 256 * EPT - 1) / (256 * EPT), batch);
     if (variant == 1) hipLaunchKernelGGL(bisect_kernel, grid, dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
     else if (variant == 2) hipLaunchKernelGGL(bisect2_kernel, grid, dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
-    else if (ept3 == 8) hipLaunchKernelGGL(bisect3_kernel<8>, dim3((n + 256 * 8 - 1) / (256 * 8), batch), dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw);
-    else hipLaunchKernelGGL(bisect3_kernel<4>, grid, dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw);
+    else if (ept3 == 8) hipLaunchKernelGGL(bisect3_kernel<8>, dim3((n + 256 * 8 - 1) / (256 * 8), batch), dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw, opts().bisect_tail);
+    else hipLaunchKernelGGL(bisect3_kernel<4>, grid, dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw, opts().bisect_tail);
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }

