@@ -498,6 +498,38 @@ struct Sb7Shared {
 // Two workgroups (two CUs of one XCD) per channel, as in v6: this workgroup runs sweeps first, first + 4, ...
 // (half A) and first + 1, first + 5, ... (half B); the partner runs the two sweeps in between.  Half A's
 // tiles then come from what the PARTNER's half B stored; `prog` carries B's progress across.
+//
+// THE HAND-OFF BETWEEN RING MEMBERS, against the valid forms of MI355X_MICROARCH.md ("Workgroup dispatch, XCD placement &
+// inter-workgroup visibility").  Data: band tiles in HBM-backed memory; producer = half B of member w-1, consumer =
+// half A of member w; flag = prog[w-1] (sweep << 20 | items finished).
+//   Placement is VERIFIED, not assumed: every member reports HW_REG_XCC_ID in the handshake word; unless all P ids are
+//   equal the ring is dissolved and member 0 runs the channel alone (mode 2 below; also on a handshake time-out).
+//   So producer and consumer always share one XCD, i.e. ONE L2, which is the coherence point of their CUs.
+//   Producer  (guide: plain stores -> every storing wave's vmcnt(0) -> barrier -> [agent release] -> relaxed agent flag):
+//     plain global stores of the tiles (the vector L1 is write-through: the bytes are in the XCD's L2 once the store
+//     has been acknowledged) -> `s_waitcnt vmcnt(0)` in EVERY wave of half B one super-step later, at the top of its
+//     next P5 where the wait is free (or in the idle path) -> barrier 0 of the following super-step -> lane 0: `__hip_atomic_store(relaxed, agent)` of the progress word
+//     (global_store ... sc1).  The agent release (`buffer_wbl2 sc1`: write the L2's dirty lines back to memory) of
+//     the guide's form is what makes bytes visible to ANOTHER XCD's L2; within one XCD the consumer reads the same
+//     L2 the stores went to, so it is omitted -- at 1.7-6.5 us per fence it would cost as much as the super-step
+//     (5.9 us) it would be issued in.  This is the one deliberate departure from the copyable form, and the reason
+//     the XCD check above is mandatory rather than a speed hint.
+//   Consumer  (guide: ONE relaxed poll -> ONE agent acquire -> vmcnt(0) -> barrier -> plain loads):
+//     lane 0 polls with `__hip_atomic_load(relaxed, agent)` (global_load sc1: served by the L2, never by the L1); the
+//     value goes through LDS (SH.pw) and is acted on only after the next workgroup barrier.  The acquire
+//     (`buffer_inv sc1` + `s_waitcnt vmcnt(0)`, every wave of half A) is issued ONCE PER SWEEP, before the sweep's
+//     first tile load (ACT_PRELOAD), not once per poll.  Why that suffices: a line of this CU's L1 can be stale only
+//     if it was filled before the producer's store.  (i) Lines filled during this CU's previous pass over the band
+//     are dropped by the per-sweep invalidate.  (ii) Within the sweep, the load of item j is issued only when the
+//     published progress is >= j + margin (margin = 3), i.e. after the producer's stores of items <= j+2 were
+//     acknowledged by the L2; a tile's 128-byte lines reach at most 15 rows into item j+1's tile, never further, so no
+//     line is filled ahead of its producer.  Tile loads of half A are plain loads for speed (sc1 loads measured
+//     +18 %: tile rows straddle lines); the final d, e read-out of member 0 uses sc1 loads (ld_sc1) because it
+//     follows no invalidate.
+//   What guards it: bit-identical spectra across repeated 128-channel solves and across ring sizes 2/4/8, one
+//   workgroup per channel, and both fallbacks (tests/test_gpu_solve.py::test_sb2st_fallback_paths,
+//   ::test_full_size_batch_is_deterministic); a stale line shows up there as a difference.
+//
 // control block of one channel for v7/v8: a RING of P <= SB8_MAXP workgroups (P CUs of one XCD).  Member w runs the
 // sweeps 2w + 2P t (half A) and 2w + 1 + 2P t (half B); half A's tiles come from what member w-1's half B stored.
 constexpr int SB8_MAXP = 8;

@@ -321,19 +321,22 @@ __device__ __forceinline__ bool bracket_final(double lo, double hi)
     return (mid <= lo) || (mid >= hi) || (hi - lo <= 2.0 * 2.220446049250313e-16 * fmax(fabs(lo), fabs(hi)) + 1e-300);
 }
 
-// dynamic LDS of bisect3_kernel<EPT> for n rows
-static size_t bisect3_lds_bytes(int n, int ept)
+// dynamic LDS of bisect3_kernel<EPT, TPB> for n rows (ng = TPB * EPT evaluation slots)
+static size_t bisect3_lds_bytes(int n, int ng)
 {
-    const int np = (n + HW - 1) / HW * HW, ng = 256 * ept;
+    const int np = (n + HW - 1) / HW * HW;
     return (size_t)(np + 1) * 16 + (size_t)(ng / 2) * 16 + (size_t)ng * 4 + (size_t)(ng / 2) * 4;
 }
 
-template <int EPT>
-__global__ __launch_bounds__(256) void bisect3_kernel(int n, int ldn, const double *__restrict__ dall,
+// TPB threads per workgroup: 512 = two waves per SIMD sharing one LDS copy of the matrix (one wave per SIMD reaches
+// only ~60 % of the fp64 vector rate: tools/microbench/mfma_f64_peak, v_fma_f64 line)
+template <int EPT, int TPB>
+__global__ __launch_bounds__(TPB) void bisect3_kernel(int n, int ldn, const double *__restrict__ dall,
                                                      const double *__restrict__ eall, double *wall, long ldw, int tail)
 {
     extern __shared__ double2 sde[];
-    constexpr int NG = 256 * EPT;
+    constexpr int NG = TPB * EPT;
+    constexpr int NW = TPB / 64;
     constexpr int KC = NG / 2;                         // capacity of the tail list
     const int np = (n + HW - 1) / HW * HW;
     double2 *de = sde;                                 // de[i] = (d_i, e_{i-1}^2), i = 0 .. np
@@ -341,14 +344,14 @@ __global__ __launch_bounds__(256) void bisect3_kernel(int n, int ldn, const doub
     double *lhi = llo + KC;
     int *cg = (int *)(lhi + KC);                       // counts at the NG evaluation slots
     int *lm = cg + NG;
-    __shared__ double red[8];
+    __shared__ double red[2 * NW];
     __shared__ int sK;
     const int tid = threadIdx.x;
     const size_t ch = blockIdx.y;
     const double *dg = dall + ch * (size_t)ldn, *eg = eall + ch * (size_t)ldn;
     double *wout = wall + ch * (size_t)ldw;
     double gl = 1e300, gu = -1e300;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += TPB) {
         const double di = dg[i];
         const double el = (i > 0) ? fabs(eg[i - 1]) : 0.0;
         const double er = (i < n - 1) ? fabs(eg[i]) : 0.0;
@@ -360,17 +363,17 @@ __global__ __launch_bounds__(256) void bisect3_kernel(int n, int ldn, const doub
         gl = fmin(gl, __shfl_xor(gl, off));
         gu = fmax(gu, __shfl_xor(gu, off));
     }
-    if ((tid & 63) == 0) { red[tid >> 6] = gl; red[4 + (tid >> 6)] = gu; }
+    if ((tid & 63) == 0) { red[tid >> 6] = gl; red[NW + (tid >> 6)] = gu; }
     __syncthreads();
-    gl = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
-    gu = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+#pragma unroll
+    for (int q = 0; q < NW; ++q) { gl = fmin(gl, red[q]); gu = fmax(gu, red[NW + q]); }
     const double eps = 2.220446049250313e-16;
     double tnorm = fmax(fabs(gl), fabs(gu));
     if (!(tnorm > 0.0)) tnorm = 1.0;                   // the zero matrix
     int kexp;
     (void)frexp(tnorm, &kexp);                         // tnorm = f 2^kexp, f in [0.5, 1)
     const double sc = ldexp(1.0, -kexp), isc = ldexp(1.0, kexp);
-    for (int i = tid; i <= np; i += 256) {
+    for (int i = tid; i <= np; i += TPB) {
         // row i of the scaled matrix with its coupling to row i-1.  Padding rows: d = 2, coupling at the floor.
         const double di = (i < n) ? dg[i] * sc : 2.0;
         const double ev = (i >= 1 && i < n) ? (eg[i - 1] * sc) : 0.0;
@@ -380,22 +383,22 @@ __global__ __launch_bounds__(256) void bisect3_kernel(int n, int ldn, const doub
     gl = gl * sc - 2.1 * eps * n - 1e-300;             // scaled Gershgorin interval, widened as dstebz does
     gu = gu * sc + 2.1 * eps * n + 1e-300;
 
-    const int mbase = blockIdx.x * NG + tid;           // eigenvalue indices mbase + 256 c
+    const int mbase = blockIdx.x * NG + tid;           // eigenvalue indices mbase + TPB c
     double lo[EPT], hi[EPT];
     {
-        // first level: NG interior points x_j = gl + (gu - gl) (j+1)/(NG+1), j = tid + 256 c
+        // first level: NG interior points x_j = gl + (gu - gl) (j+1)/(NG+1), j = tid + TPB c
         const double w = gu - gl;
         double xg[EPT];
         int cc[EPT];
 #pragma unroll
-        for (int c = 0; c < EPT; ++c) xg[c] = gl + w * ((double)(tid + 256 * c + 1) * (1.0 / (NG + 1)));
+        for (int c = 0; c < EPT; ++c) xg[c] = gl + w * ((double)(tid + TPB * c + 1) * (1.0 / (NG + 1)));
         sturm_counts3<EPT>(de, np, xg, cc);
 #pragma unroll
-        for (int c = 0; c < EPT; ++c) cg[tid + 256 * c] = cc[c];
+        for (int c = 0; c < EPT; ++c) cg[tid + TPB * c] = cc[c];
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < EPT; ++c) {
-            const int m = mbase + 256 * c;
+            const int m = mbase + TPB * c;
             int L = -1, R = NG;                        // count(x_L) <= m < count(x_R), with x_{-1} = gl, x_NG = gu
             while (R - L > 1) {
                 const int mid = (L + R) >> 1;
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(256) void bisect3_kernel(int n, int ldn, const doub
 #pragma unroll
         for (int c = 0; c < EPT; ++c) {
             mid[c] = 0.5 * (lo[c] + hi[c]);
-            done[c] = (mbase + 256 * c >= n) || bracket_final(lo[c], hi[c]);
+            done[c] = (mbase + TPB * c >= n) || bracket_final(lo[c], hi[c]);
             nun += done[c] ? 0 : 1;
         }
         if (!__syncthreads_or(nun > (tail ? EPT / 2 : 0))) break;
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(256) void bisect3_kernel(int n, int ldn, const doub
 #pragma unroll
         for (int c = 0; c < EPT; ++c) {
             if (!done[c]) {
-                if (cnt[c] > mbase + 256 * c) hi[c] = mid[c]; else lo[c] = mid[c];
+                if (cnt[c] > mbase + TPB * c) hi[c] = mid[c]; else lo[c] = mid[c];
             }
         }
     }
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(256) void bisect3_kernel(int n, int ldn, const doub
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < EPT; ++c) {
-        const int m = mbase + 256 * c;
+        const int m = mbase + TPB * c;
         done[c] = (m >= n) || bracket_final(lo[c], hi[c]);
         if (!done[c]) {
             const int pos = atomicAdd(&sK, 1);
@@ -449,20 +452,20 @@ __global__ __launch_bounds__(256) void bisect3_kernel(int n, int ldn, const doub
         int cc[EPT];
 #pragma unroll
         for (int c = 0; c < EPT; ++c) {
-            const int s = tid + 256 * c, e = s / P, q = s - e * P;
+            const int s = tid + TPB * c, e = s / P, q = s - e * P;
             x[c] = 2.0;                                // idle slot: a point above the spectrum
             if (e < K) { const double a = llo[e]; x[c] = msect_point(a, lhi[e] - a, q, rp); }
         }
         sturm_counts3<EPT>(de, np, x, cc);
 #pragma unroll
-        for (int c = 0; c < EPT; ++c) cg[tid + 256 * c] = cc[c];
+        for (int c = 0; c < EPT; ++c) cg[tid + TPB * c] = cc[c];
         __syncthreads();
         double nlo[EPT / 2], nhi[EPT / 2];
         int nm[EPT / 2];
         bool keep[EPT / 2];
 #pragma unroll
         for (int j = 0; j < EPT / 2; ++j) {
-            const int e = tid + 256 * j;
+            const int e = tid + TPB * j;
             keep[j] = false;
             if (e < K) {
                 const double a = llo[e], b = lhi[e], w = b - a;
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(256) void bisect3_kernel(int n, int ldn, const doub
     }
     {   // round limit (not reached: every round shrinks every bracket): store what is left
         const int K = min(sK, KC);
-        for (int e = tid; e < K; e += 256) wout[lm[e]] = 0.5 * (llo[e] + lhi[e]) * isc;
+        for (int e = tid; e < K; e += TPB) wout[lm[e]] = 0.5 * (llo[e] + lhi[e]) * isc;
     }
 }
 
@@ -674,10 +677,14 @@ int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_
     // Eight eigenvalues per thread when that still fills the GPU (>= 256 workgroups): the same speed as four (measured
     // 15.7 against 15.6 ms), but one workgroup per CU instead of two, so that half of every CU's LDS stays free
     // for the one-wave kernels of the consumed eigenvector that run beside this one.
+    // 2048 eigenvalues per workgroup: four per thread on 512 threads when that still fills the GPU (>= 256 workgroups),
+    // else 1024 per workgroup (four per thread on 256 threads).  BSP_BISECT_EPT = 8: eight per thread on 256 threads
+    // (round 1's choice), 4: four per thread on 256 threads.
     const int ept_env = opts().bisect_ept;
-    int ept3 = (ept_env == 4 || ept_env == 8) ? ept_env : ((((n + 2047) / 2048) * batch >= 256) ? 8 : 4);
-    if (bisect3_lds_bytes(n, ept3) > 150 * 1024) ept3 = 4;          // n = 8192: 146 KB with four per thread
-    const size_t lds3 = bisect3_lds_bytes(n, ept3);
+    int mode = (ept_env == 8) ? 8 : (ept_env == 4) ? 4 : ((((n + 2047) / 2048) * batch >= 256) ? 512 : 4);
+    int ng = (mode == 4) ? 1024 : 2048;
+    if (bisect3_lds_bytes(n, ng) > 150 * 1024) { mode = 4; ng = 1024; }          // n = 8192: 146 KB with 1024 slots
+    const size_t lds3 = bisect3_lds_bytes(n, ng);
     const size_t lds = (size_t)2 * (n + 3 * RS + HW) * sizeof(double);    // variants 1 and 2
     if (lds3 > 150 * 1024) return BSP_ERR_UNSUPPORTED;
     static bool attr_set = false;
@@ -687,17 +694,24 @@ int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect2_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect3_kernel<4>),
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect3_kernel<4, 256>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect3_kernel<8>),
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect3_kernel<8, 256>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect3_kernel<4, 512>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
     const dim3 grid((n + 256 * EPT - 1) / (256 * EPT), batch);
     if (variant == 1) hipLaunchKernelGGL(bisect_kernel, grid, dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
     else if (variant == 2) hipLaunchKernelGGL(bisect2_kernel, grid, dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
-    else if (ept3 == 8) hipLaunchKernelGGL(bisect3_kernel<8>, dim3((n + 256 * 8 - 1) / (256 * 8), batch), dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw, opts().bisect_tail);
-    else hipLaunchKernelGGL(bisect3_kernel<4>, grid, dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw, opts().bisect_tail);
+    else {
+        const dim3 g3((n + ng - 1) / ng, batch);
+        const int tail = opts().bisect_tail;
+        if (mode == 512) hipLaunchKernelGGL((bisect3_kernel<4, 512>), g3, dim3(512), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
+        else if (mode == 8) hipLaunchKernelGGL((bisect3_kernel<8, 256>), g3, dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
+        else hipLaunchKernelGGL((bisect3_kernel<4, 256>), g3, dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
+    }
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }
