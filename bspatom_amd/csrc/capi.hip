@@ -56,6 +56,7 @@ const OptName OPT_TABLE[] = {
     {"gemm_diag", "BSP_GEMM_DIAG", &Options::gemm_diag}, {"bisect", "BSP_BISECT", &Options::bisect},
     {"bisect_ept", "BSP_BISECT_EPT", &Options::bisect_ept},
     {"bisect_tail", "BSP_BISECT_TAIL", &Options::bisect_tail}, {"no_eigvec_prefetch", "BSP_NO_EIGVEC_PREFETCH", &Options::no_eigvec_prefetch},
+    {"poison_c", "BSP_POISON_C", &Options::poison_c},
 };
 }  // namespace
 
@@ -307,6 +308,7 @@ int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const d
 {
     int rc;
     if ((rc = launch_band_cholesky(n, k, d_SB, b.UB, b.rdiag, b.info, st))) return rc;
+    if (opts().poison_c) BSP_HIP(hipMemsetAsync(b.C, 0xFF, (size_t)nl * npad * npad * sizeof(double), st));
     if ((rc = launch_standard_form(n, npad, k, nl, d_HB, b.UB, b.rdiag, b.Y, b.C, st))) return rc;
     if (ev) BSP_HIP(hipEventRecord(ev[1], st));
     Sy2sbWork w;
@@ -630,7 +632,7 @@ extern "C" int bspatom_stage_standard_form(int n, int k, int nl, const double *S
     BSP_HIP(hipMemset(dinfo, 0, sizeof(int)));
     BSP_HIP(hipMemset(dY.p, 0, (size_t)nl * np * np * sizeof(double)));
     if ((rc = launch_band_cholesky(n, k, dSB.p, dUB.p, dr.p, dinfo, 0))) return rc;
-    if ((rc = launch_standard_form(n, np, k, nl, dHB.p, dUB.p, dr.p, dY.p, dC.p, 0))) return rc;
+    if ((rc = launch_standard_form(n, np, k, nl, dHB.p, dUB.p, dr.p, dY.p, dC.p, 0, 1))) return rc;
     BSP_HIP(hipDeviceSynchronize());
     int hi = 0;
     BSP_HIP(hipMemcpy(&hi, dinfo, sizeof(int), hipMemcpyDeviceToHost));

@@ -49,6 +49,8 @@ struct Options {
     int bisect = 3, bisect_ept = 0;
     int bisect_tail = 1;         // BSP_BISECT_TAIL: 0 = lock-step bisection to the end (no multisection tail), for A/B timing
     int no_eigvec_prefetch = 0;
+    int poison_c = 0;            // test hook: fill the dense C buffer with NaN bit patterns before every solve (nothing outside the
+                                 // blocks the standard form writes may ever be read)
 };
 Options &opts();
 
@@ -101,8 +103,9 @@ int launch_dipole_bands(int nfun, int k, int ka, int nkp, const double *d_ptab, 
 // bandchol.hip
 int launch_band_cholesky(int n, int k, const double *d_SB, double *d_UB, double *d_rdiag, int *d_info,
                          hipStream_t st);
+// full = 0: C's lower triangle and first block super-diagonal only (all the reduction reads); 1: the whole matrix
 int launch_standard_form(int n, int npad, int k, int nl, const double *d_HB, const double *d_UB,
-                         const double *d_rdiag, double *d_Y, double *d_C, hipStream_t st);
+                         const double *d_rdiag, double *d_Y, double *d_C, hipStream_t st, int full = 0);
 // sy2sb.hip
 struct Sy2sbWork {
     double *buf2;   // second [V | Z | V] set (panels alternate: look-ahead QR writes one while the update reads the other)

@@ -681,7 +681,7 @@ int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_
     // else 1024 per workgroup (four per thread on 256 threads).  BSP_BISECT_EPT = 8: eight per thread on 256 threads
     // (round 1's choice), 4: four per thread on 256 threads.
     const int ept_env = opts().bisect_ept;
-    int mode = (ept_env == 8) ? 8 : (ept_env == 4) ? 4 : ((((n + 2047) / 2048) * batch >= 256) ? 512 : 4);
+    int mode = (ept_env == 8) ? 8 : (ept_env == 4) ? 4 : (ept_env == 2) ? 1024 : ((((n + 2047) / 2048) * batch >= 256) ? 512 : 4);
     int ng = (mode == 4) ? 1024 : 2048;
     if (bisect3_lds_bytes(n, ng) > 150 * 1024) { mode = 4; ng = 1024; }          // n = 8192: 146 KB with 1024 slots
     const size_t lds3 = bisect3_lds_bytes(n, ng);
@@ -700,6 +700,8 @@ int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect3_kernel<4, 512>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect3_kernel<2, 1024>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
     const dim3 grid((n + 256 * EPT - 1) / (256 * EPT), batch);
@@ -709,6 +711,7 @@ int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_
         const dim3 g3((n + ng - 1) / ng, batch);
         const int tail = opts().bisect_tail;
         if (mode == 512) hipLaunchKernelGGL((bisect3_kernel<4, 512>), g3, dim3(512), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
+        else if (mode == 1024) hipLaunchKernelGGL((bisect3_kernel<2, 1024>), g3, dim3(1024), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
         else if (mode == 8) hipLaunchKernelGGL((bisect3_kernel<8, 256>), g3, dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
         else hipLaunchKernelGGL((bisect3_kernel<4, 256>), g3, dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
     }

@@ -728,3 +728,17 @@ def test_dipole_matelem_file(tmp_path):
     iu = np.triu_indices(2 * n1)
     assert n1r == n1 and np.allclose(back[iu], z[iu], rtol=1e-9, atol=1e-300)
     prob.close()
+
+
+def test_reduction_reads_only_the_valid_blocks_of_C():
+    """The standard form writes C's lower triangle and first block super-diagonal only (bandchol.hip); everything else
+    of the dense buffer is stale.  With the buffer poisoned with NaN bit patterns before the solve the spectra must not
+    change by a bit -- at n = 1024 (several panels), n = 200 (padding rows) and for the 128-wide tiles of a batch."""
+    for name, nl in (("c3_1024_l31", 5), ("lin256", 4), ("c1_lin", 2)):
+        prob = capi.Problem(input_from_case(name))
+        E0, info = prob.solve(0, nl)
+        with _Options(poison_c=1):
+            E1, info1 = prob.solve(0, nl)
+        assert np.all(info == 0) and np.all(info1 == 0)
+        assert np.all(np.isfinite(E1)) and np.array_equal(E0, E1), name
+        prob.close()

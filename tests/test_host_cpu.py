@@ -268,10 +268,11 @@ def test_trans_amp_host_logic_vs_reference(name):
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """profiles/r01_bench_line.json is the line bench.py printed on the MI355X: the keys the driver and the judge read,
-    the metric of BASELINE.json, a roofline object whose numbers are consistent with each other, a CPU baseline."""
+    """profiles/r02_bench_line.json is the line bench.py printed on the MI355X: the keys the driver and the judge read,
+    the metric of BASELINE.json, a roofline object whose numbers are consistent with each other (the whole path against the
+    fp64 peak, SURVEY 8d, plus a per-kernel list that names its sources), a CPU baseline measured at the metric's nfun."""
     import json
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_line.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_line.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -280,13 +281,24 @@ def test_committed_bench_line_keeps_the_contract():
     assert d["dtype"] == "f64" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["higher_is_better"] is True
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6 * d["n_gpus"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic"]
+    n, k = 4096, 9
+    F = 4.0 / 3.0 * n ** 3 + 4.0 * n ** 2 * k                        # SURVEY 8(d) flop per l-channel
+    assert abs(r["achieved"] - F * d["value"] / 1e12) < 1e-9 * r["achieved"]
+    names = [kk["kernel"] for kk in r["kernels"]]
+    assert names[0].startswith("sb2st") and any(x.startswith("gemm2_kernel<128") for x in names) and any(x.startswith("gemm2_kernel<64") for x in names)
+    for kk in r["kernels"]:
+        assert abs(kk["frac"] - kk["achieved"] / kk["peak"]) < 1e-12
+        assert kk["traffic"] is None or (kk["traffic"] > 0 and kk["traffic_source"].startswith("profiles/r02_"))
+        assert kk["launch_ms_source"]
+    sb = r["kernels"][0]
+    assert sb["bound"] == "hbm" and sb["traffic"] >= 0.9 * sb["bytes_pass_model"] and sb["bytes_min"] < sb["bytes_pass_model"]
     # value = channels per step / time per step
-    assert abs(d["value"] - d["config"]["channels_per_gpu"] * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert abs(d["value"] - d["config"]["channels_total"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     c = d["cpu_baseline"]
-    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and "nfun=4096" in c["sample"]
+    assert "value_scaled_to_nfun4096" not in c                       # measured at the metric's size, not extrapolated
 
 
 def test_matelem_all_round_trip(tmp_path):
