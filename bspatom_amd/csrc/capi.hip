@@ -187,6 +187,15 @@ extern "C" int bspatom_problem_create(const bspatom_input *in, int device, bspat
         fprintf(stderr, "bspatom: no HIP device %d (libbspatom has no CPU path)\n", device);
         return BSP_ERR_NOGPU;
     }
+    // One process per GPU: the kernels' opt-ins for large LDS, the side streams of sy2sb and the stage-level
+    // scratch buffers are created once per process on the device of the first problem.
+    static int first_device = -1;
+    if (first_device < 0) first_device = device;
+    if (device != first_device) {
+        fprintf(stderr, "bspatom: this process already works on device %d; use one process per GPU (device %d refused)\n",
+                first_device, device);
+        return BSP_ERR_UNSUPPORTED;
+    }
     bspatom_problem *p = new (std::nothrow) bspatom_problem;
     if (!p) return BSP_ERR_ARG;
     p->device = device;

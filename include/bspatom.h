@@ -51,7 +51,8 @@ int bspatom_host_setup(const bspatom_input *in, bspatom_sizes *s, double *rt, do
                        double *wg);
 /* Creates the problem on HIP device `device`: derives sizes (ReadInputs.f90:39-141), builds the knot
  * sequence and Aind (grid.f90:14-91), the Gauss-Legendre rule (Modules.f90:112-153) and the
- * potential table (Modules.f90:263-295) on the host, uploads them. */
+ * potential table (Modules.f90:263-295) on the host, uploads them.  One process per GPU: every problem of a
+ * process must name the device of the first one (BSPATOM_ERR_UNSUPPORTED otherwise). */
 int bspatom_problem_create(const bspatom_input *in, int device, bspatom_problem **out);
 void bspatom_problem_destroy(bspatom_problem *p);
 int bspatom_problem_sizes(const bspatom_problem *p, bspatom_sizes *s);
