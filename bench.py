@@ -99,7 +99,15 @@ def profile_summary(channels, nfun):
             break
         except Exception:
             continue
-    return pmc, pmc_file, stats, stats_file
+    mfma, mfma_file = {}, None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mfma_util.json")), reverse=True):
+        try:
+            mfma = {k.replace("bsp::", ""): v for k, v in json.load(open(f))["kernels"].items()}
+            mfma_file = os.path.relpath(f, ROOT)
+            break
+        except Exception:
+            continue
+    return pmc, pmc_file, stats, stats_file, mfma, mfma_file
 
 
 def main():
@@ -210,7 +218,7 @@ def main():
         b = 64
         F = 4.0 / 3.0 * n ** 3 + 4.0 * n ** 2 * args.k            # SURVEY 8(d) flops per l-channel
         names = ["assemble", "chol_std", "sy2sb", "sb2st", "bisect"]
-        pmc, pmc_file, kstats, stats_file = profile_summary(nl, n)
+        pmc, pmc_file, kstats, stats_file, mfma, mfma_file = profile_summary(nl, n)
 
         def pmc_bytes(kname):
             if not pmc:
@@ -247,12 +255,18 @@ def main():
             calls = sum(v[1] for _, v in hit)
             steps_prof = 5.0                                      # tools/refresh_profiles.sh: --steps 4 --warmup 1
             per_step_ms = tot_ms / steps_prof
+            # achieved: the MFMA pipe's busy share of the kernel running ALONE (counter pass, profiles/*_mfma_util.json:
+            # SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles) x peak; in the pipeline the launches of two channel groups overlap,
+            # so the sum of their durations (kernel_ms_per_step) exceeds the wall time they occupy
+            util = next((v["mfma_util"] for k, v in mfma.items() if k.startswith(kname)), None)
+            ach = util * FP64_PEAK_TFLOPS if util is not None else flop / (per_step_ms * 1e-3) / 1e12
             kern.append({"kernel": kname + ", ...>", "what": label, "bound": "mfma", "launches_per_step": calls / steps_prof,
                          "kernel_ms_per_step": per_step_ms, "launch_ms_source": stats_file,
-                         "flop_per_step": flop, "achieved": flop / (per_step_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": flop / (per_step_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                         "traffic": pmc_bytes(kname), "traffic_source": pmc_file,
-                         "note": "sum of launch durations per step; two channel groups overlap, so sums exceed wall time"})
+                         "flop_per_step": flop, "achieved": ach, "peak": FP64_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
+                         "achieved_source": (mfma_file + " (MFMA pipe busy, kernel alone)") if util is not None else "flop / sum of overlapped launch durations",
+                         "tflops_from_overlapped_launch_sums": flop / (per_step_ms * 1e-3) / 1e12,
+                         "traffic": pmc_bytes(kname), "traffic_source": pmc_file})
         # the path as a whole, SURVEY 8(d): F(n) flop per l-channel against the fp64 peak of the GPUs used
         ach = F * value / 1e12
         roof = {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS * world, "unit": "TFLOP/s",

@@ -26,6 +26,33 @@ def test_library_exports_every_declared_symbol():
     assert set(capi.EXPORTS) == names
 
 
+def test_lapack_shim_exports_dsygv():
+    """libbspatom_lapack.so (csrc/lapack_shim.c): the plain LAPACK name the reference's link line resolves
+    (matrices.f90:248, src/Makefile:23), forwarding to bsp_dsygv_; nothing else is exported under a LAPACK name.
+    Without a GPU the call reports LAPACK's 'failed' class (info = n), never a silent zero."""
+    import ctypes as C
+    import subprocess
+    so = os.path.join(ROOT, "bspatom_amd", "libbspatom_lapack.so")
+    assert os.path.exists(so), "run make -C bspatom_amd/csrc"
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    defined = [l.split()[-1] for l in syms.split("\n") if l.strip()]
+    assert "dsygv_" in defined and not [d for d in defined if d.endswith("_") and d != "dsygv_"]
+    L = C.CDLL(so)
+    n = 4
+    a = np.eye(n, order="F"); b = np.eye(n, order="F"); w = np.zeros(n); work = np.zeros(16)
+    it = C.c_int(1); nn = C.c_int(n); ld = C.c_int(n); lw = C.c_int(-1); info = C.c_int(7)
+    L.dsygv_.restype = None
+    args = lambda: (C.byref(it), C.c_char_p(b"V"), C.c_char_p(b"U"), C.byref(nn), a.ctypes.data_as(C.c_void_p), C.byref(ld),
+                    b.ctypes.data_as(C.c_void_p), C.byref(ld), w.ctypes.data_as(C.c_void_p), work.ctypes.data_as(C.c_void_p),
+                    C.byref(lw), C.byref(info), C.c_size_t(1), C.c_size_t(1))
+    L.dsygv_(*args())
+    assert info.value == 0 and work[0] == 3 * n - 1                  # workspace query needs no device
+    if capi.lib().bspatom_device_count() == 0:
+        lw.value = 16
+        L.dsygv_(*args())
+        assert info.value == n
+
+
 def test_no_gpu_means_loud_failure():
     if capi.lib().bspatom_device_count() > 0:
         pytest.skip("a GPU is present")
