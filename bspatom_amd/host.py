@@ -430,3 +430,120 @@ def dipole_matelem(prob, channels, n1_max, kind_pi=1, mph=0):
                 D = prob.dipole_elements(l0, nj, lf, 1, n1_max, coef)
                 z[a_ * n1_max: (a_ + 1) * n1_max, b_ * n1_max + nj - 1, 0] = c0 * D
     return z
+
+
+# ---- KIND_PI = 0 on several GPUs: one process per GPU, channels sharded, spectra gathered ---------------
+def write_structure_outputs(nfun, lmax, E, l_ini, wf, outdir):
+    """Enl.dat, wf_n0.dat and the stdout text of a KIND_PI = 0 run from the spectra E[l][i] and the tabulated initial
+    state wf = (r, u) (matrices.f90:239-265,388-391; Bsp_Atom.f90:118-146) -- the formatting half of `run`."""
+    out = ["PROGRAM TO CALCULATE ELECTRONIC STRUCTURE AND PI CROSS SECTIONS,".rjust(64), "  USING B-SPLINES", ""]
+    out.append("Number of B-spline Functions / l: nfun =%5d" % nfun)
+    out.append("\nMax. Angular Momenta Included: l_max =%3d" % lmax)
+    with open(os.path.join(outdir, "Enl.dat"), "w") as f:
+        f.write(" %d\n" % nfun)
+        for l in range(lmax + 1):
+            out.append("\n l0 = %2d" % l)
+            out.append(" HC = ESC eigenvalue solved\n")
+            out.append("    n   Eigenvalues")
+            out.append("    -   -----------")
+            for i in range(nfun):
+                txt = fortran_g(E[l][i], 22, 15)
+                if i < 20:
+                    out.append(" %4d  %s" % (i + 1 + l, txt))
+                f.write(" %4d  %s\n" % (i + 1, txt))
+            if l == l_ini:
+                out.append("\nWriting down Initial State WF\n")
+                with open(os.path.join(outdir, "wf_n0.dat"), "w") as g:
+                    for ri, ui in zip(*wf):
+                        g.write(fortran_g(ri, 20, 10) + fortran_g(ui, 20, 10) + "\n")
+    os.makedirs(os.path.join(outdir, "CSs"), exist_ok=True)
+    out.append("\nProgram Finished!")
+    return "\n".join(out)
+
+
+def run_sharded(text, outdir=".", npts=10000, solver=None):
+    """`Bsp_Atom_omp.x < bsp_0.inp` (KIND_PI = 0) on the GPUs of one node: started once per GPU by
+    `python -m torch.distributed.run --nproc-per-node N -m bspatom_amd.host < bsp_0.inp`.  Rank r solves the block of
+    l-channels `parallel.channel_range` gives it (the channels are independent, matrices.f90:242-248), the spectra are
+    all-gathered (RCCL with backend nccl, gloo without a GPU), the rank that owns l_ini computes the consumed eigenvector
+    and its WRITE_WF table and broadcasts them, rank 0 writes the files.  Output identical to `run`.
+    solver(l0, nl) -> (E[nl][nfun], wf-or-None) replaces the GPU solve in the CPU tests."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from . import parallel
+    if kind_pi_from_namelist(text) != 0:
+        raise ValueError("run_sharded covers KIND_PI = 0 (the hot path); the other branches run on one GPU")
+    inp = input_from_namelist(text)
+    sizes = capi.host_setup(inp, arrays=False)
+    nfun, lmax = sizes.nfun, sizes.lmax
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    counts = [parallel.channel_range(r, world, lmax)[1] for r in range(world)]
+    l0, nl = parallel.channel_range(rank, world, lmax)
+    owner = next(r for r in range(world) if sum(counts[:r]) <= inp.l_ini < sum(counts[:r + 1]))
+    use_gpu = solver is None
+    dev = torch.device("cuda", torch.cuda.current_device()) if use_gpu else torch.device("cpu")
+    wf = None
+    if use_gpu:
+        prob = capi.Problem(inp, dev.index)
+        E_loc = torch.zeros(max(nl, 1) * nfun, dtype=torch.float64, device=dev)
+        if nl > 0:
+            info = prob.solve_dev(l0, nl, E_loc.data_ptr())
+            if info.any():
+                raise RuntimeError(" ERROR DIAGONALIZING THE MATRIX! %s (l = %d ..)" % (list(info), l0))
+        if rank == owner:
+            c = prob.eigvec(inp.l_ini, inp.n0_ini)
+            wf = prob.write_wf(c, npts)
+        prob.close()
+    else:
+        E_np, wf = solver(l0, nl)
+        E_loc = torch.zeros(max(nl, 1) * nfun, dtype=torch.float64)
+        E_loc[: nl * nfun] = torch.from_numpy(np.ascontiguousarray(E_np, dtype=np.float64).reshape(-1))
+    E_all = parallel.gather_spectra(E_loc[: nl * nfun], nfun, counts)
+    wft = torch.zeros(2 * (npts + 1), dtype=torch.float64, device=dev)
+    if rank == owner:
+        wft[: npts + 1] = torch.from_numpy(np.asarray(wf[0])).to(dev)
+        wft[npts + 1:] = torch.from_numpy(np.asarray(wf[1])).to(dev)
+    if world > 1:
+        dist.broadcast(wft, src=owner)
+    if rank != 0:
+        return None
+    E = E_all.cpu().numpy()
+    w = wft.cpu().numpy()
+    return E, write_structure_outputs(nfun, lmax, E, inp.l_ini, (w[: npts + 1], w[npts + 1:]), outdir)
+
+
+def _main():
+    """torchrun entry: namelist on stdin of EVERY rank (torch.distributed.run forwards stdin to rank 0 only, so the text
+    can also come from the file named by BSPATOM_INPUT)."""
+    import sys
+    import torch
+    import torch.distributed as dist
+    path = os.environ.get("BSPATOM_INPUT")
+    text = open(path).read() if path else sys.stdin.read()
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    # RCCL writes its banner to stdout when the communicator is created: keep the program's stdout clean (it is compared
+    # with the reference's), everything else goes to stderr
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
+    if launched:
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            raise SystemExit("bspatom_amd.host needs an MI355X per rank: libbspatom has no CPU path")
+    r = run_sharded(text, outdir=os.environ.get("BSPATOM_OUTDIR", "."))
+    if r is not None:
+        sys.stdout.flush()
+        os.write(real_stdout, (r[1] + "\n").encode())
+    if launched:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    _main()

@@ -30,3 +30,25 @@ def test_bench_under_torchrun_one_rank(scaling):
     assert d["rydberg_max_rel_err_n<=8"] < 1e-4        # n = 8 reaches the wall of the rb = 200 box (1.5e-5); n <= 4: 1e-10
     r = d["roofline"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernels"][0]["kernel"].startswith("sb2st")
+
+
+def test_sharded_host_under_torchrun(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 1 -m bspatom_amd.host` (the multi-GPU KIND_PI = 0 host at N = 1:
+    RCCL initialised, spectra through parallel.gather_spectra): Enl.dat, wf_n0.dat and stdout byte for byte what the
+    single-process Python host writes for the same input."""
+    import numpy as np
+    from conftest import golden_input
+    inp = golden_input("lin256")
+    out1 = tmp_path / "sharded"; out1.mkdir()
+    port = 29950 + os.getpid() % 40
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "bspatom_amd.host"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BSPATOM_INPUT=inp, BSPATOM_OUTDIR=str(out1), PYTHONPATH=ROOT)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    from bspatom_amd import host
+    out2 = tmp_path / "single"; out2.mkdir()
+    E, c, text = host.run(open(inp).read(), outdir=str(out2))
+    assert open(out1 / "Enl.dat").read() == open(out2 / "Enl.dat").read()
+    assert open(out1 / "wf_n0.dat").read() == open(out2 / "wf_n0.dat").read()
+    assert p.stdout.rstrip("\n") == text.rstrip("\n")

@@ -169,6 +169,57 @@ def test_l_sharding_and_gather_gloo(tmp_path, case):
     assert all(p.returncode == 0 for p in procs), outs
 
 
+_SHARDED_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from bspatom_amd import host
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=world)
+g = np.load(%(gold)r)
+E = g["E"]; text = str(g["namelist"])
+npts = 200
+rr = np.linspace(0.0, 50.0, npts + 1); uu = np.sin(rr) * np.exp(-0.1 * rr)
+l_ini = int(%(l_ini)d)
+def solver(l0, nl):            # stand-in for the GPU solve of this rank's channels: the reference's spectra
+    return E[l0:l0 + nl].copy(), ((rr, uu) if l0 <= l_ini < l0 + nl else None)
+out = host.run_sharded(text, outdir=%(out)r, npts=npts, solver=solver)
+assert (out is None) == (rank != 0)
+if rank == 0:
+    assert np.array_equal(out[0], E)
+    open(os.path.join(%(out)r, "stdout.txt"), "w").write(out[1])
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("case,l_ini", [("simfues", 0), ("c1_lin", 1)])      # 5 channels over 2 ranks (3 + 2); owner of l_ini = rank 0
+def test_sharded_host_gloo(tmp_path, case, l_ini):
+    """host.run_sharded (the multi-GPU KIND_PI = 0 host) with world size 2 over gloo: channel blocks from
+    parallel.channel_range, spectra through parallel.gather_spectra, the owner's wave-function table broadcast, rank 0
+    writes -- the files must be what the single-process writer produces from the same spectra."""
+    from bspatom_amd import host
+    port = 29700 + os.getpid() % 2000
+    script = tmp_path / "worker.py"
+    outd = tmp_path / "out"; outd.mkdir()
+    gold = os.path.join(ROOT, "tests", "golden", case + ".npz")
+    script.write_text(_SHARDED_WORKER % dict(root=ROOT, port=port, gold=gold, out=str(outd), l_ini=l_ini))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    g = np.load(gold)
+    E = g["E"]; nch, nfun = E.shape
+    ref = tmp_path / "ref"; ref.mkdir()
+    rr = np.linspace(0.0, 50.0, 201); uu = np.sin(rr) * np.exp(-0.1 * rr)
+    text = host.write_structure_outputs(nfun, nch - 1, E, int(l_ini), (rr, uu), str(ref))
+    assert open(outd / "Enl.dat").read() == open(ref / "Enl.dat").read()
+    assert open(outd / "wf_n0.dat").read() == open(ref / "wf_n0.dat").read()
+    assert open(outd / "stdout.txt").read() == text
+    assert os.path.isdir(outd / "CSs")
+
+
 def test_channel_range_partitions():
     from bspatom_amd.parallel import channel_range
     for world in (1, 2, 3, 8):
