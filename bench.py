@@ -253,7 +253,7 @@ def main():
                 continue
             tot_ms = sum(v[0] * v[1] for _, v in hit)            # all launches of all steps of the profiled run
             calls = sum(v[1] for _, v in hit)
-            steps_prof = 5.0                                      # tools/refresh_profiles.sh: --steps 4 --warmup 1
+            steps_prof = 5.0                                      # tools/gpu_profiles.sh: --steps 4 --warmup 1
             per_step_ms = tot_ms / steps_prof
             # achieved: the MFMA pipe's busy share of the kernel running ALONE (counter pass, profiles/*_mfma_util.json:
             # SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles) x peak; in the pipeline the launches of two channel groups overlap,

@@ -11,6 +11,6 @@ python3 tools/pmc_summary.py $O/fetch $O/write $O/pmc_summary.json 128 4096 > $O
 python3 tools/mfma_util.py $O/mfma $O/mfma_util.json > $O/mfma_util.txt
 cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
 find $O -name '*kernel_trace.csv' -delete; find $O -name '*agent_info.csv' -delete; find $O -name '*counter_collection.csv' -delete
-(make -C tools/microbench > /dev/null 2>&1 && cd tools/microbench && for w in 1 2 4; do echo "# mfma_f64_peak, $w workgroup(s) of 4 waves per CU"; ./mfma_f64_peak $w; done; echo "# gemm_core"; ./gemm_core; echo "# tile_bw"; ./tile_bw) > $O/microbench.txt 2>&1
+(make -C tools/microbench > /dev/null 2>&1 && cd tools/microbench && for w in 1 2 4; do echo "# mfma_f64_peak, $w workgroup(s) of 4 waves per CU"; ./mfma_f64_peak $w; done; echo "# gemm_core"; ./gemm_core; echo "# tile_bw"; ./tile_bw; echo "# sturm_rate (512 threads)"; ./sturm_rate 512) > $O/microbench.txt 2>&1
 python3 bench.py > $O/bench_line.json 2> $O/bench.err
 head -12 $O/kernel_stats.csv | cut -c1-160; cat $O/pmc_summary.txt; cat $O/mfma_util.txt; tail -c 900 $O/bench_line.json
