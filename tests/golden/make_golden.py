@@ -291,6 +291,39 @@ def run_case(name, text, store_mats):
     print("%-10s nfun=%5d k=%2d lmax=%2d  E1=%.15g  asm %.2fs solve %.2fs wall %.1fs" % (
         name, nfun, k, lmax, out["E"][0, 0], out["ref_time_assembly_s"][0], out["ref_time_solve_s"][0], wall), flush=True)
 
+# Spectra-only fixtures from the reference PROGRAM itself (oracle/_ref/Bsp_Atom_ref.x, no dump driver: the dense dump of
+# Uij(nfun,nfun,0:lmax) would be 17 GB at C4): BASELINE configs[2] and configs[3] at their real sizes, every channel.
+SPECTRA = {
+    # C3: Hydrogen l = 0..31 batched, N_bsp = 2048 (32 x ~13 s of DSYGV)
+    "c3_2048_l31": nml("KIND_GRID=0 ra=0.0D0 rb=400.0D0 k=9 nfun=2048", "n0_ini=1 l_ini=0 l_fin=31 Zatom=1.0D0"),
+    # C4: Hydrogen l = 0..127, N_bsp = 4096 -- the bench workload, all 128 channels (~3.5 h of DSYGV on 8 cores)
+    "c4_4096_l127": nml("KIND_GRID=0 ra=0.0D0 rb=800.0D0 k=9 nfun=4096", "n0_ini=1 l_ini=0 l_fin=127 Zatom=1.0D0"),
+}
+
+def run_spectra(name, text):
+    refprog = os.path.join(ROOT, "oracle", "_ref", "Bsp_Atom_ref.x")
+    inp = os.path.join(HERE, "inputs", name + ".inp")
+    with open(inp, "w") as f:
+        f.write("! golden-fixture input '%s' (generated by make_golden.py)\n" % name)
+        f.write(text)
+    with tempfile.TemporaryDirectory(prefix="bspgold.") as tmp:
+        t0 = time.time()
+        with open(inp) as fin:
+            p = subprocess.run([refprog], stdin=fin, cwd=tmp, capture_output=True, text=True)
+        wall = time.time() - t0
+        if p.returncode != 0 or "Program Finished!" not in p.stdout:
+            raise RuntimeError("reference failed on %s:\n%s\n%s" % (name, p.stdout[-2000:], p.stderr[-2000:]))
+        lines = open(os.path.join(tmp, "Enl.dat")).read().split("\n")
+        nfun = int(lines[0])
+        vals = np.array([float(l.split()[1]) for l in lines[1:] if l.strip()])
+        E = vals.reshape(-1, nfun)
+        wf = np.loadtxt(os.path.join(tmp, "wf_n0.dat"))
+        out = dict(sizes=np.array([nfun, 0, 0, 0, 0, 0, 0, E.shape[0] - 1]), E=E, wf_idx=np.arange(0, 10001, 50), wf_rows=wf[::50].copy(),
+                   ref_wall_s=np.array([wall]), namelist=np.array(open(inp).read()),
+                   source=np.array("oracle/_ref/Bsp_Atom_ref.x (the reference program, unmodified sources, LAPACK 3.12): Enl.dat"))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("%-14s nfun=%5d channels=%3d  E1=%.15g  wall %.0f s" % (name, nfun, E.shape[0], E[0, 0], wall), flush=True)
+
 def main():
     if not os.path.exists(REFX):
         sys.exit("oracle/_ref/ref_dump.x missing: run oracle/ref/build_ref.sh first")
@@ -307,6 +340,11 @@ def main():
         args.remove("--amp")
         for name in (args or list(AMP)):
             run_amp(name, AMP[name])
+        return
+    if "--spectra" in args:
+        args.remove("--spectra")
+        for name in (args or list(SPECTRA)):
+            run_spectra(name, SPECTRA[name])
         return
     if "--pi3" in args:
         args.remove("--pi3")
