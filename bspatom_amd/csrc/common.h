@@ -38,7 +38,8 @@ namespace bsp {
 struct Options {
     int sb2st_version = 8;       // BSP_SB2ST_VERSION: 8 = two-sweep workgroups in rings, 7 = one per channel, 3 = one sweep per workgroup
     int sb2st_ring = 0;          // BSP_SB2ST_RING: ring size (0 = by channel count)
-    int sb2st_margin = 3, sb2st_hyst = 2, sb2st_lead = 16;
+    int sb2st_margin = 3, sb2st_hyst = 2;
+    int sb2st_lead = 0;          // BSP_SB2ST_LEAD: 0 = by ring size (pairs: 8, larger rings: 16; re-scan of round 2)
     int sb2st_check = 0;         // BSP_SB2ST_CHECK: synchronise and report ring formation / holds on stderr
     int sb2st_diag = 0;          // BSP_SB2ST_DIAG: instrumented kernel
     int sb2st_force_abort = 0;   // test hook: 1 = every ring ABORTs its handshake (member 0 runs alone); 2 = pretend the

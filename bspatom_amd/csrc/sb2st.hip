@@ -1346,7 +1346,8 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
         const int nblk = (ver == 8) ? ((batch + 7) / 8) * 8 * P : batch;
         const size_t lds = (sizeof(Sb7Shared) + 1023) / 1024 * 1024;
         // measured: holds 13k -> 1.6k per channel with the lead 16; 243 ms (hyst 2) .. 258 ms (hyst 16)
-        const int diag7 = opts().sb2st_diag, margin = opts().sb2st_margin, lead = opts().sb2st_lead, hyst = opts().sb2st_hyst;
+        const int diag7 = opts().sb2st_diag, margin = opts().sb2st_margin, hyst = opts().sb2st_hyst;
+        const int lead = opts().sb2st_lead > 0 ? opts().sb2st_lead : (P == 2 ? 8 : 16);   // pairs: 216 -> 210 ms at 128 channels with 8
         const int fab = opts().sb2st_force_abort;
         if (diag7) {
             long long *dbuf = nullptr, h[96];

@@ -45,6 +45,8 @@ CASES = {
     "simfues": None, "bc1": None, "ka_ra": None, "yuk256": None,          # the other small linear-grid cases
     "bc1_2048": None, "sf2048": None, "exp2048": None, "explin2048": None,  # SURVEY 8(f).4 at scale
     "c5_8192": None,                                                       # BASELINE configs[4] at its real size
+    "c3_2048_l31": None,                                                   # BASELINE configs[2] at its real size, all 32 channels
+    "c4_4096_l127": None,                                                  # BASELINE configs[3]: all 128 channels of the bench workload
 }
 
 

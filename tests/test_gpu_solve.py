@@ -796,3 +796,38 @@ def test_sb2st_handoff_under_uneven_load():
     note("sb2st hand-off under uneven load: 2 x (128 channels rings of 2, 32 channels rings of 8 and 4) bit-identical to the quiet run; timing of the last %s"
          % prob.last_timing())
     prob.close()
+
+
+def test_c3_at_full_size_all_channels():
+    """BASELINE configs[2] AT ITS REAL SIZE: Hydrogen l = 0..31 batched, N_bsp = 2048, k = 9 -- every one of the 32 channels
+    against the spectra the reference PROGRAM wrote (oracle/_ref/Bsp_Atom_ref.x, tests/golden/c3_2048_l31.npz: its Enl.dat)
+    and against the 113-bit truth of 39 eigenvalues per channel; wf_n0.dat against the reference's file."""
+    g = load_golden("c3_2048_l31")
+    inp = input_from_case("c3_2048_l31")
+    prob = capi.Problem(inp)
+    E, info = prob.solve(0, 32)
+    assert np.all(info == 0)
+    note("c3_2048_l31 timing %s -> %.1f eigensolves/s" % (prob.last_timing(), 32e3 / prob.last_timing()["total"]))
+    truth = load_truth("c3_2048_l31")
+    for l in range(32):
+        full_size_bar(E[l], g["E"][l], "solve c3_2048_l31 l=%d" % l, truth[l])
+    c = prob.eigvec(inp.l_ini, inp.n0_ini)
+    r, u = prob.write_wf(c)
+    rows = g["wf_rows"]; idx = g["wf_idx"]
+    sgn = np.sign(np.dot(u[idx], rows[:, 1]))
+    assert np.max(np.abs(sgn * u[idx] - rows[:, 1])) <= 2e-8 * np.max(np.abs(rows[:, 1]))
+    prob.close()
+
+
+def test_c4_all_128_channels_vs_reference():
+    """BASELINE configs[3], THE BENCH WORKLOAD, every channel: Hydrogen l = 0..127, N_bsp = 4096, k = 9 against the spectra the
+    reference PROGRAM wrote for all 128 channels (tests/golden/c4_4096_l127.npz: ~3.5 h of LAPACK DSYGV on 8 cores in the build
+    container) and the 113-bit truth of the eigenvalues nearest zero of every channel."""
+    g = load_golden("c4_4096_l127")
+    prob = capi.Problem(input_from_case("c4_4096_l127"))
+    E, info = prob.solve(0, 128)
+    assert np.all(info == 0)
+    truth = load_truth("c4_4096_l127")
+    for l in range(128):
+        full_size_bar(E[l], g["E"][l], "solve c4_4096_l127 l=%d" % l, truth[l])
+    prob.close()
