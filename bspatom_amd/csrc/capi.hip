@@ -155,6 +155,10 @@ static int upload(T **dst, const T *src, size_t count)
 static int problem_init(bspatom_problem *p, const bspatom_input *in, int device)
 {
     if (derive(*in, &p->hs) != 0) return BSP_ERR_ARG;
+    if (p->hs.nfun > 8256) {          // the dense -> band stage holds a panel in one workgroup (sy2sb.hip), the bisection the
+        fprintf(stderr, "bspatom: nfun = %d exceeds the 8256 functions per channel this build supports\n", p->hs.nfun);   // matrix in LDS
+        return BSP_ERR_UNSUPPORTED;
+    }
     build_grid(&p->hs);
     build_vpot(&p->hs);
     p->device = device;

@@ -46,6 +46,12 @@ int derive(const bspatom_input &in, HostSetup *h)
     if (in.kind_grid < 0 || in.kind_grid > 2 || in.kind_pot < 0 || in.kind_pot > 2) return -2;
     if (in.kind_grid == 2 && (h->nintv_exp < 2 || h->nintv_lin < 1)) return -2;
     if (in.kind_grid == 1 && nointv < 2) return -2;
+    // A box of no extent or not-a-number parameters: the reference runs on (all knots coincide, BSPLVB STOPs with
+    // 'FATAL ERROR' or the matrices fill with NaN); here they are an argument error before anything is launched.
+    if (!std::isfinite(in.ra) || !std::isfinite(in.rb) || !std::isfinite(in.rmax) || !std::isfinite(in.zatom) ||
+        !std::isfinite(in.emax_fin) || !(in.rb > in.ra)) return -2;
+    if (in.kind_grid == 1 && !(h->gsize > 0.01)) return -2;                  // exponential grid: first interior knot at 0.01 (grid.f90:35)
+    if (in.n0_ini < 1 || in.l_ini < 0 || in.l_fin < 0 || h->lmax < 0) return -2;
     h->ntot = 0;
     for (int i = 0; i < 3; ++i) { h->alphan[i] = 0.0; h->numn[i] = 0; }
     for (int i = 0; i < 4; ++i) h->bl[i] = 0.0;

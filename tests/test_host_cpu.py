@@ -94,6 +94,16 @@ def test_host_setup_rejects_bad_input():
         capi.host_setup(capi.make_input(kind_grid=0, rb=10.0, k=7, nfun=3))       # nfun < k
     with pytest.raises(capi.BspAtomError):
         capi.host_setup(capi.make_input(kind_grid=5, rb=10.0, k=7, nfun=30))
+    # a box of no extent, rb < ra, not-a-number, an exponential grid shorter than its first interior knot, n0_ini = 0:
+    # the reference runs into BSPLVB's STOP or NaN matrices with these; here they are argument errors up front
+    for kw in (dict(kind_grid=0, rb=0.0, k=7, nfun=64), dict(kind_grid=0, ra=60.0, rb=50.0, k=7, nfun=64),
+               dict(kind_grid=0, rb=float("nan"), k=7, nfun=64), dict(kind_grid=0, rb=50.0, zatom=float("inf"), k=7, nfun=64),
+               dict(kind_grid=1, ra=0.0, rb=0.005, k=7, nfun=64), dict(kind_grid=0, rb=50.0, k=7, nfun=64, n0_ini=0),
+               dict(kind_grid=0, rb=50.0, k=7, nfun=64, l_ini=-1), dict(kind_grid=0, rb=50.0, k=7, nfun=64, ka=100),
+               dict(kind_grid=2, rb=50.0, rmax=100.0, k=7, nfun=64), dict(kind_grid=0, rb=50.0, k=7, nfun=64, kind_pot=7)):
+        with pytest.raises(capi.BspAtomError) as ei:
+            capi.host_setup(capi.make_input(**kw))
+        assert ei.value.code == -2, kw
 
 
 def test_namelist_reference_input():
