@@ -538,6 +538,15 @@ def test_panel_qr_first_kernel_matches_second():
     prob.close()
 
 
+def test_sizes_beyond_the_build_are_refused_at_create():
+    """nfun > 8256: the panel of the dense -> band stage no longer fits one workgroup and the tridiagonal matrix no longer
+    fits the LDS of the bisection; refused when the problem is created (BSPATOM_ERR_UNSUPPORTED), not in the middle of a solve."""
+    with pytest.raises(capi.BspAtomError) as ei:
+        capi.Problem(capi.make_input(kind_grid=0, rb=800.0, k=9, nfun=8320))
+    assert ei.value.code == -5
+    capi.Problem(capi.make_input(kind_grid=0, rb=800.0, k=9, nfun=8256)).close()
+
+
 def test_unknown_option_is_rejected():
     with pytest.raises(capi.BspAtomError):
         capi.set_option("no_such_switch", 1)
