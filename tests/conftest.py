@@ -24,7 +24,8 @@ def golden_input(name):
     return os.path.join(GOLDEN, "inputs", name + ".inp")
 
 
-SMALL_CASES = ["bsp0", "c1_exp", "c1_lin", "rogers", "simfues", "bc1", "ka_ra", "lin256", "yuk256"]
+SMALL_CASES = ["bsp0", "c1_exp", "c1_lin", "rogers", "simfues", "bc1", "ka_ra", "lin256", "yuk256",
+               "tiny8", "n65_k4", "n128", "bc10"]      # round 2: shapes at the edges of the kernels' tilings
 
 
 def ulp_diff(a, b):

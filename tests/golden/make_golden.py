@@ -53,6 +53,13 @@ CASES = {
     "lin256": (nml("KIND_GRID=0 ra=0.0D0 rb=50.0D0 k=9 nfun=256", "n0_ini=1 l_ini=0 l_fin=3 Zatom=1.0D0"), True),
     "yuk256": (nml("KIND_GRID=0 ra=0.0D0 rb=25.0D0 k=11 nfun=256", "n0_ini=1 l_ini=0 l_fin=0 Zatom=20.0D0 KIND_POT=1"), True),
     "lin1024": (nml("KIND_GRID=0 ra=0.0D0 rb=200.0D0 k=9 nfun=1024", "n0_ini=2 l_ini=0 l_fin=1 Zatom=1.0D0"), False),
+    # shapes at the edges of the kernels' tilings (round 2): nfun barely above k (one knot interval more than the order needs),
+    # nfun = 65 and 128 (one row over a 64-block / exactly two blocks: one panel of the dense -> band stage), k = 4 (ka = 7, odd),
+    # asymmetric boundary conditions (first B-spline kept, last one dropped)
+    "tiny8": (nml("KIND_GRID=0 ra=0.0D0 rb=12.0D0 k=5 nfun=8", "n0_ini=1 l_ini=0 l_fin=1 Zatom=1.0D0"), True),
+    "n65_k4": (nml("KIND_GRID=0 ra=0.0D0 rb=40.0D0 k=4 nfun=65", "n0_ini=1 l_ini=0 l_fin=1 Zatom=1.0D0"), True),
+    "n128": (nml("KIND_GRID=0 ra=0.0D0 rb=60.0D0 k=8 nfun=128", "n0_ini=2 l_ini=1 l_fin=2 Zatom=2.0D0"), True),
+    "bc10": (nml("KIND_GRID=0 ra=0.0D0 rb=30.0D0 k=6 nfun=50 KIND_BC1=1 KIND_BC2=0", "n0_ini=1 l_ini=0 l_fin=1 Zatom=1.0D0"), True),
 }
 BIG = {
     # C3 corners: channels l = 30, 31 of the 32-channel batch (lmax=31 would store 32 spectra; l_ini selects nothing new),
