@@ -117,7 +117,11 @@
       REAL(DP) :: T3ja, T3jb, c0, c1, c2, An, d1, d2, csl, M_au, cc0, cc1, Ef, avec(3)
       REAL(DP), ALLOCATABLE :: dip(:), T_fi(:)
       REAL(DP), PARAMETER :: PI = 3.141592653589793238462643D0, c_au = 137.03599913815D0, a_au = 5.29177249D-9
+      REAL(DP), PARAMETER :: I0_au = 3.50944758D16
       REAL(DP), EXTERNAL :: W3J
+!     stdout echo of READ_INPUTS / SEL_LM (the numbers a run prints before MATRIX_SVT starts)
+      INTEGER :: nshell(3), ntot_el, ifib, fa, fb, fc, ntf, ntf2, nsel, il, im, la
+      REAL(DP) :: rog(3,0:3), xn, ssum, Epump, Eprobe, kph
 
       WRITE(6,'(A64)') 'PROGRAM TO CALCULATE ELECTRONIC STRUCTURE AND PI CROSS SECTIONS,'
       WRITE(6,'(A17,/)') '  USING B-SPLINES'
@@ -157,6 +161,7 @@
         STOP 1
       END IF
       rc = bspatom_problem_sizes(prob, sz)
+!     ---- what READ_INPUTS prints (ReadInputs.f90:54,67,71,93,127,186-202,222,236-271), in its order ----
       IF( KIND_GRID == 2 ) THEN
         WRITE(6,'(/,A29,I5)') 'Initial Number of Functions: ', nfun
         WRITE(6,'(A29,I5)') 'Number of functions changed: ', sz%nfun
@@ -165,8 +170,136 @@
       lmax = sz%lmax
       WRITE(6,'(A40,I5)') 'Number of B-spline Functions / l: nfun =', nfun
       WRITE(6,'(/,A38,I3)') 'Max. Angular Momenta Included: l_max =', lmax
+      IF( KIND_POT == 1 ) THEN
+!       Rogers screening parameters, echoed list-directed as the reference does (:95-128)
+        nshell = (/ 2, 8, 8 /)
+        rog = 0.D0
+        rog(1,0:2) = (/ 0.8855D0, 0.2549D0, -0.0901D0 /)
+        rog(2,0:2) = (/ 0.3386D0, 1.1323D0, -0.4904D0 /)
+        rog(3,0:3) = (/ 0.1437D0, 0.9129D0, -0.6940D0, 0.2503D0 /)
+        ntot_el = 0
+        DO i = 1, 3
+          ntot_el = ntot_el + nshell(i)
+          xn = DBLE(Zatom - ntot_el)
+          IF( xn == 0.D0 ) xn = 1.D0
+          ssum = 0.D0
+          DO l = 0, 3
+            ssum = ssum + rog(i,l) / (xn**l)
+          END DO
+          WRITE(6,*) i, xn, (xn + 1.D0) * ssum
+        END DO
+      END IF
+      WRITE(6,'(/,A17)') 'Field Parameters:'
+      IF( A0 /= 0.D0 ) WRITE(6,'(A4,G12.5)') 'A0 =', A0
+      IF( I0 /= 0.D0 ) WRITE(6,'(A4,G12.5)') 'I0 =', I0
+      IF( w0 /= 0.D0 ) WRITE(6,'(A4,G12.5)') 'w0 =', w0
+      IF( b0 /= 0.D0 ) WRITE(6,'(A4,G12.5)') 'b0 =', b0
+      IF( Eph /= 0.D0 ) WRITE(6,'(A5,G12.5)') 'Eph =', Eph
+      IF( A01 /= 0.D0 ) WRITE(6,'(A5,G12.5)') 'A01 =', A01
+      IF( I01 /= 0.D0 ) WRITE(6,'(A5,G12.5)') 'I01 =', I01
+      IF( moam /= 0 ) WRITE(6,'(A20,I3)') 'Topological Charge =', moam
+      IF( afocus /= 0.D0 ) WRITE(6,'(A22,G12.5)') 'Focusing angle (Deg.):', afocus
+      IF( ncyc /= 0 ) WRITE(6,'(A18,I3)') 'Num. Opt. Cycles =', ncyc
+      IF( KIND_SCP == 1 ) WRITE(6,'(A25)') 'Lorenz Scalar-Potential Included'
+      IF( KIND_TD /= 0 ) WRITE(6,'(A19,I2)') 'Runge--Kutta Order:', KIND_RK
+      IF( t_delay /= 0.D0 ) WRITE(6,'(A11,G12.5,A3)') 'Time-Delay:', t_delay, ' fs'
+      IF( A0x /= 0.D0 ) WRITE(6,'(A18)') 'Laser Pulse Pol. x'
+      IF( A0y /= 0.D0 ) WRITE(6,'(A18)') 'Laser Pulse Pol. y'
+      IF( A0z /= 0.D0 ) WRITE(6,'(A18)') 'Laser Pulse Pol. z'
+      IF( nfib >= 0 ) THEN
+        ifib = 0                                          ! Fibonacci number nfib (Modules.f90:947-973)
+        IF( nfib == 1 .OR. nfib == 2 ) ifib = 1
+        IF( nfib >= 3 ) THEN
+          fa = 1; fb = 1
+          DO i = 3, nfib
+            fc = fa + fb; fa = fb; fb = fc
+          END DO
+          ifib = fb
+        END IF
+        WRITE(6,'(A41,I5)') 'Number of Pts for Fibonacci sampling Pts:', ifib
+      END IF
+      Epump = SQRT(I0 / I0_au)
+      Eprobe = 0.D0
+      IF( KIND_PI >= 8 .AND. KIND_POT == 0 ) THEN
+        ntf = 20
+        Eph = 0.5D0 * ((1.D0/(DBLE(n0_ini)**2)) - 1.D0/(DBLE(ntf)**2))
+        ncyc = CEILING(DBLE((ntf**2-n0_ini**2)) / DBLE(n0_ini**2-ntf**2+(n0_ini*ntf)**2))
+        ncyc = MAX(ncyc,10)
+        WRITE(6,'(A31,I5)') 'Modified Num. Opt. Cycles Pump:', ncyc
+        WRITE(6,'(A28,G14.7)') 'Modified Photon Energy Pump:', Eph
+        IF( I01 == 0.D0 ) I01 = I0
+        Eprobe = SQRT(I01 / I0_au)
+        IF( Eph2 == -1.D0 ) THEN
+          Eph2 = Eph
+          ncyc2 = ncyc
+        ELSE
+          ntf2 = ntf + 10
+          Eph2 = 0.5D0 * ((1.D0/(DBLE(ntf)**2)) - 1.D0/(DBLE(ntf2)**2))
+          ncyc2 = CEILING(DBLE((ntf2**2-ntf**2)) / DBLE(ntf**2-ntf2**2+(ntf*ntf2)**2))
+        END IF
+        ncyc2 = MAX(ncyc2,2)
+        WRITE(6,'(A32,I5)') 'Modified Num. Opt. Cycles Probe:', ncyc2
+        WRITE(6,'(A29,G14.7)') 'Modified Photon Energy Probe:', Eph2
+      ELSE IF( KIND_POT /= 0 ) THEN
+        Eprobe = SQRT(I01 / I0_au)
+        kph = Eph2 / c_au
+        WRITE(6,'(A31,I5)') 'Modified Num. Opt. Cycles Pump:', ncyc
+        WRITE(6,'(A28,G14.7)') 'Modified Photon Energy Pump:', Eph
+        WRITE(6,'(A32,I5)') 'Modified Num. Opt. Cycles Probe:', ncyc2
+        WRITE(6,'(A29,G14.7)') 'Modified Photon Energy Probe:', Eph2
+        WRITE(6,'(A28,G14.7)') 'Modified Photon Wave Number:', kph
+      END IF
+      WRITE(6,'(A7,G14.7)') 'Epump =', Epump
+      WRITE(6,'(A8,G14.7)') 'Eprobe =', Eprobe
+!     ---- GRID (grid.f90:25,33,46-47,65-66) ----
+      IF( KIND_GRID == 0 ) THEN
+        WRITE(6,'(A23)') 'Linear Knotpts Sequence'
+      ELSE IF( KIND_GRID == 1 ) THEN
+        WRITE(6,'(A29)') 'Exponential Knotpts Sequence'
+      ELSE
+        WRITE(6,'(/,A35)') 'Exponential-Linear Knotpts Sequence'
+        WRITE(6,'(A30,G12.5)') 'Limit of Exp. Sequence: rmax =', rmax
+      END IF
       WRITE(6,'(/,A22,I6)') 'Number of Knot Points:' , sz%nkp
       WRITE(6,'(A27,2I3)') 'Multiplicity of END points:', sz%nbc1, sz%nbc2
+!     ---- SEL_LM (grid.f90:113-236): the (l, m) of the final states, by KIND_PI ----
+      WRITE(6,'(/,A22)') 'Selecting Final States'
+      WRITE(6,'(/,A22)') 'Selected final states:'
+      WRITE(6,'(T3,A1,T7,A2,T12,A2)') 'i', 'lf', 'mf'
+      WRITE(6,'(T2,A12)') '------------'
+      nsel = 0
+      IF( KIND_PI == 0 ) THEN
+        WRITE(6,'(T1,I3,T6,I3,T11,I3)') 1, l_ini, m_ini
+      ELSE IF( KIND_PI <= 2 ) THEN                      ! dipolar: l0 - 1 (if it exists and can carry m0) and l0 + 1
+        DO il = l_ini - 1, l_ini + 1, 2
+          IF( il >= 0 .AND. il >= m_ini ) THEN
+            nsel = nsel + 1
+            WRITE(6,'(T1,I3,T6,I3,T11,I3)') nsel, il, m_ini
+          END IF
+        END DO
+      ELSE IF( KIND_PI == 5 .OR. KIND_PI == 6 .OR. ((KIND_PI == 8 .OR. KIND_PI == 9) .AND. KIND_NLM == 0) ) THEN
+        DO il = 0, lmax                                   ! every l that can carry m0
+          IF( il >= ABS(m_ini) ) THEN
+            nsel = nsel + 1
+            WRITE(6,'(T1,I3,T6,I3,T11,I3)') nsel, il, m_ini
+          END IF
+        END DO
+      ELSE IF( (KIND_PI == 8 .OR. KIND_PI == 9) .AND. KIND_NLM == 1 ) THEN
+        DO il = 0, lmax                                   ! unpolarised initial state: |m| <= min(l, l0)
+          la = MIN(il, l_ini)
+          DO im = -la, la
+            nsel = nsel + 1
+            WRITE(6,'(T1,I3,T6,I3,T11,I3)') nsel, il, im
+          END DO
+        END DO
+      ELSE IF( .NOT. (KIND_PI == 8 .OR. KIND_PI == 9) ) THEN
+        DO il = 0, lmax                                   ! all (l, m)
+          DO im = -il, il
+            nsel = nsel + 1
+            WRITE(6,'(T1,I3,T6,I3,T11,I3)') nsel, il, im
+          END DO
+        END DO
+      END IF
       WRITE(6,'(/,A34)') 'Calculating S, V, U and T Matrices'
 
       ALLOCATE( En(nfun*(lmax+1)), info(lmax+1), ci(nfun) )

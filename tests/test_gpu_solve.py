@@ -853,3 +853,40 @@ def test_c4_all_128_channels_vs_reference():
     for l in range(128):
         full_size_bar(E[l], g["E"][l], "solve c4_4096_l127 l=%d" % l, truth[l])
     prob.close()
+
+
+@pytest.mark.parametrize("name", ["c1_lin", "bsp0", "rogers", "simfues", "c1_exp", "bc10"])
+def test_fortran_host_full_stdout(tmp_path, name):
+    """The WHOLE stdout of `bsp_atom_host.x < input` against the reference's for KIND_PI = 0, line by line: everything READ_INPUTS
+    (sizes, the Rogers parameters list-directed, the 'Field Parameters:' block, Fibonacci points, Epump / Eprobe), GRID (knot
+    sequence, knot points, multiplicities), SEL_LM (the table of final states), MATRIX_SVT and SOLVE_SYSTEM print
+    (ReadInputs.f90:54-271, grid.f90:25-66,113-236, matrices.f90:52,194,256-265).  The fixture's text comes from the dump
+    driver, which calls the reference's routines but is not its main program: the banner (Bsp_Atom.f90) and 'Program
+    Finished!' are checked separately.  Eigenvalue lines: same labels, values to 1e-13 of lambda_max; all others identical."""
+    import subprocess, re
+    exe = os.path.join(ROOT, "bspatom_amd", "bsp_atom_host.x")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran host not built (no flang)")
+    g = load_golden(name)
+    with open(golden_input(name)) as fin:
+        p = subprocess.run([exe], stdin=fin, cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    mine = [l.rstrip() for l in p.stdout.rstrip("\n").split("\n")]
+    assert mine[0].strip() == "PROGRAM TO CALCULATE ELECTRONIC STRUCTURE AND PI CROSS SECTIONS," and mine[1] == "  USING B-SPLINES" and mine[2] == ""
+    assert mine[-1].strip() == "Program Finished!" and mine[-2] == ""
+    mine = mine[3:-2]
+    ref = [l.rstrip() for l in str(g["stdout"]).rstrip("\n").split("\n") if not l.startswith("REF_TIME")]
+    while ref and ref[-1] == "":
+        ref.pop()
+    while mine and mine[-1] == "":
+        mine.pop()
+    lam = np.max(np.abs(g["E"]))
+    eig = re.compile(r"^\s+(\d+)\s+(-?\d*\.\d+(E[+-]\d+)?)$")
+    assert len(mine) == len(ref), "\n".join(mine[:60]) + "\n---\n" + "\n".join(ref[:60])
+    for a, b in zip(mine, ref):
+        ma, mb = eig.match(a), eig.match(b)
+        if ma and mb:
+            assert ma.group(1) == mb.group(1) and len(a) == len(b)
+            assert abs(float(ma.group(2)) - float(mb.group(2))) <= 1e-13 * lam + 1e-15 * abs(float(mb.group(2)))
+        else:
+            assert a == b, (a, b)
