@@ -855,7 +855,8 @@ def test_c4_all_128_channels_vs_reference():
     prob.close()
 
 
-@pytest.mark.parametrize("name", ["c1_lin", "bsp0", "rogers", "simfues", "c1_exp", "bc10"])
+@pytest.mark.parametrize("name", ["c1_lin", "bsp0", "rogers", "simfues", "c1_exp", "bc10", "pi3_emax1", "pi5_emax05", "pi8_emax1",
+                                  "pi3_nobound"])
 def test_fortran_host_full_stdout(tmp_path, name):
     """The WHOLE stdout of `bsp_atom_host.x < input` against the reference's for KIND_PI = 0, line by line: everything READ_INPUTS
     (sizes, the Rogers parameters list-directed, the 'Field Parameters:' block, Fibonacci points, Epump / Eprobe), GRID (knot
@@ -873,14 +874,20 @@ def test_fortran_host_full_stdout(tmp_path, name):
     assert p.returncode == 0, p.stdout + p.stderr
     mine = [l.rstrip() for l in p.stdout.rstrip("\n").split("\n")]
     assert mine[0].strip() == "PROGRAM TO CALCULATE ELECTRONIC STRUCTURE AND PI CROSS SECTIONS," and mine[1] == "  USING B-SPLINES" and mine[2] == ""
-    assert mine[-1].strip() == "Program Finished!" and mine[-2] == ""
-    mine = mine[3:-2]
+    if name.startswith("pi"):            # KIND_PI >= 3 (Field block with I0 / Eph, SEL_LM's full (l, m) table, the 'Modified ...'
+        mine = mine[3:]                  # lines of KIND_PI >= 8, state limits, n1_max): the host stops where SOLVE_SYSTEM returns
+    else:
+        assert mine[-1].strip() == "Program Finished!" and mine[-2] == ""
+        mine = mine[3:-2]
     ref = [l.rstrip() for l in str(g["stdout"]).rstrip("\n").split("\n") if not l.startswith("REF_TIME")]
     while ref and ref[-1] == "":
         ref.pop()
     while mine and mine[-1] == "":
         mine.pop()
     lam = np.max(np.abs(g["E"]))
+    # KIND_PI >= 3: MATRIX_SVT first calls ZINT_TH (angular integrals of the beam branches, outside SURVEY 8), which announces
+    # itself; the host does not compute them and does not print their line
+    ref = [l for l in ref if not l.startswith("REF_") and l != "Calculating Integrals Over th"]
     eig = re.compile(r"^\s+(\d+)\s+(-?\d*\.\d+(E[+-]\d+)?)$")
     assert len(mine) == len(ref), "\n".join(mine[:60]) + "\n---\n" + "\n".join(ref[:60])
     for a, b in zip(mine, ref):
