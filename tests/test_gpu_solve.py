@@ -24,7 +24,7 @@ def load_truth(name):
     return {int(l): (t["idx"][t["chan"] == l], t["hi"][t["chan"] == l]) for l in np.unique(t["chan"])}
 
 
-def full_size_bar(E, Eref, tag, truth=None):
+def full_size_bar(E, Eref, tag, truth=None, judge=None):
     """Linear-grid parity bar (north_star: every eigenvalue within 1e-10 relative of reference DSYGV).
       (1) normwise |dE| <= 1e-13 lambda_max, every eigenvalue;
       (2) |dE| <= 1e-10 |E_ref| for every eigenvalue, EXCEPT where the reference's own LAPACK value is not determined
@@ -32,7 +32,10 @@ def full_size_bar(E, Eref, tag, truth=None):
           nearest zero), and there the GPU value must be as close to the truth as the reference's own noise level
           in that channel allows:  |E_gpu - truth| <= 1e-10 |E| + 2 max_{near zero} |E_ref - truth|.
       (3) measured against the TRUTH, the GPU spectrum misses 1e-10 relative at no more eigenvalues than the
-          reference's does (+1: two LAPACK drivers differ by one on these pencils)."""
+          reference's does (+1: two LAPACK drivers differ by one on these pencils).
+    `judge(indices) -> truth` (optional) computes the 113-bit truth of further eigenvalues on the spot: an exception outside the
+    stored set is then adjudicated the same way instead of failing (128 channels at n = 4096: LAPACK's error exceeds 1e-10
+    relative at scattered eigenvalues up to |E| ~ 0.3, too many and too irregular to store them all)."""
     lam = np.max(np.abs(Eref))
     d = np.abs(E - Eref)
     rel = d / np.abs(Eref)
@@ -45,6 +48,11 @@ def full_size_bar(E, Eref, tag, truth=None):
         assert len(exc) == 0, msg
         return
     idx, tru = truth
+    extra = np.setdiff1d(exc, idx)
+    if len(extra) and judge is not None:
+        idx = np.concatenate([idx, extra]); tru = np.concatenate([tru, judge(extra)])
+        o = np.argsort(idx); idx = idx[o]; tru = tru[o]
+        msg += " (%d of them judged by truth computed on the spot)" % len(extra)
     eg = np.abs(E[idx] - tru); er = np.abs(Eref[idx] - tru)
     near = np.argsort(np.abs(tru))[:24]
     noise = np.max(er[near])
@@ -843,15 +851,35 @@ def test_c3_at_full_size_all_channels():
 
 def test_c4_all_128_channels_vs_reference():
     """BASELINE configs[3], THE BENCH WORKLOAD, every channel: Hydrogen l = 0..127, N_bsp = 4096, k = 9 against the spectra the
-    reference PROGRAM wrote for all 128 channels (tests/golden/c4_4096_l127.npz: ~3.5 h of LAPACK DSYGV on 8 cores in the build
-    container) and the 113-bit truth of the eigenvalues nearest zero of every channel."""
+    reference PROGRAM wrote for all 128 channels (tests/golden/c4_4096_l127.npz: ~3.75 h of LAPACK DSYGV on 8 cores in the build
+    container) and the 113-bit truth: stored for the eigenvalues around zero of every channel (the set is grown until the
+    reference's own error is below 3e-11 relative at its edge, 39..502 per channel), computed on the spot by the oracle's
+    quad-precision inertia count (oracle/truth_quad.c, the checker) for any exception further out."""
+    import oracle as orc
+    from oracle import truth as qt
+    from bspatom_amd.namelist import read_namelists
     g = load_golden("c4_4096_l127")
     prob = capi.Problem(input_from_case("c4_4096_l127"))
     E, info = prob.solve(0, 128)
     assert np.all(info == 0)
     truth = load_truth("c4_4096_l127")
+    bands = {}
+
+    def judge_for(l):
+        def judge(ix):
+            if not bands:
+                nl = read_namelists(open(golden_input("c4_4096_l127")).read())
+                c = orc.make_cfg(**{**nl["vars_bsp"], **nl["vars_tise"]})
+                rt, aind, xg, wg = orc.grid(c)
+                bands["SB"], bands["HB"] = orc.assemble_bands(c, rt, aind, xg, wg, 0, 128)
+            ix = np.asarray(ix, dtype=np.int32)
+            hi, lo = qt.band_eigs(bands["SB"], bands["HB"][l], ix, g["E"][l][ix], float(np.max(np.abs(g["E"][l]))),
+                                  rtol=1e-17)                  # hi alone is compared: double resolution is enough here
+            return hi
+        return judge
+
     for l in range(128):
-        full_size_bar(E[l], g["E"][l], "solve c4_4096_l127 l=%d" % l, truth[l])
+        full_size_bar(E[l], g["E"][l], "solve c4_4096_l127 l=%d" % l, truth[l], judge_for(l))
     prob.close()
 
 
