@@ -34,7 +34,7 @@ class Sizes(C.Structure):
 EXPORTS = ["bspatom_input_defaults", "bspatom_device_count", "bspatom_host_setup", "bspatom_problem_create", "bspatom_problem_destroy",
            "bspatom_problem_sizes", "bspatom_problem_grid", "bspatom_assemble", "bspatom_solve", "bspatom_solve_dev",
            "bspatom_eigvec", "bspatom_eigvecs", "bspatom_dipole_bands", "bspatom_dipole_elements", "bspatom_write_wf", "bspatom_last_timing", "bsp_dsygv_", "bspatom_stage_gemm",
-           "bspatom_stage_standard_form", "bspatom_stage_sy2sb", "bspatom_stage_sb2st", "bspatom_stage_bisect",
+           "bspatom_stage_standard_form", "bspatom_stage_sy2sb", "bspatom_stage_sb2st", "bspatom_stage_sb2sb", "bspatom_stage_bisect",
            "bspatom_set_option", "bspatom_get_option"]
 
 _lib = None
@@ -70,6 +70,7 @@ def lib():
         L.bspatom_stage_standard_form.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp]
         L.bspatom_stage_sy2sb.argtypes = [i32, i32, vp, vp]
         L.bspatom_stage_sb2st.argtypes = [i32, i32, i32, vp, vp, vp]
+        L.bspatom_stage_sb2sb.argtypes = [i32, i32, i32, vp]
         L.bspatom_stage_bisect.argtypes = [i32, i32, vp, vp, vp]
         L.bsp_dsygv_.restype = None
         L.bspatom_set_option.argtypes = [C.c_char_p, i32]
@@ -243,6 +244,14 @@ def stage_sb2st(AB, n):
     d = np.zeros((batch, npad)); e = np.zeros((batch, npad))
     _chk(lib().bspatom_stage_sb2st(n, npad, batch, _p(np.ascontiguousarray(AB)), _p(d), _p(e)), "bspatom_stage_sb2st")
     return d[:, :n], e[:, :n - 1]
+
+
+def stage_sb2sb(AB, n):
+    """First half of the two-step route: band 64 -> band 16 (returns the band array, same layout)."""
+    batch, npad, _ = AB.shape
+    out = np.ascontiguousarray(AB).copy()
+    _chk(lib().bspatom_stage_sb2sb(n, npad, batch, _p(out)), "bspatom_stage_sb2sb")
+    return out
 
 
 def stage_bisect(d, e):

@@ -695,6 +695,23 @@ extern "C" int bspatom_stage_sb2st(int n, int npad, int batch, const double *AB,
     return de.get(e, (size_t)batch * npad);
 }
 
+extern "C" int bspatom_stage_sb2sb(int n, int npad, int batch, double *AB)
+{
+    int rc;
+    if ((rc = need_gpu())) return rc;
+    DevBuf dAB;
+    if ((rc = dAB.alloc((size_t)batch * ab_stride(npad)))) return rc;
+    for (int b = 0; b < batch; ++b)
+        BSP_HIP(hipMemcpy(dAB.p + b * ab_stride(npad), AB + (size_t)b * npad * 128, (size_t)npad * 128 * sizeof(double),
+                          hipMemcpyHostToDevice));
+    if ((rc = launch_sb2sb(n, npad, batch, dAB.p, 0))) return rc;
+    BSP_HIP(hipDeviceSynchronize());
+    for (int b = 0; b < batch; ++b)
+        BSP_HIP(hipMemcpy(AB + (size_t)b * npad * 128, dAB.p + b * ab_stride(npad), (size_t)npad * 128 * sizeof(double),
+                          hipMemcpyDeviceToHost));
+    return BSP_OK;
+}
+
 extern "C" int bspatom_stage_bisect(int n, int batch, const double *d, const double *e, double *w)
 {
     int rc;

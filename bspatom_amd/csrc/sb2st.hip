@@ -1303,6 +1303,12 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
     // 8 (default): two-sweep workgroups in rings of P per channel; 7: one two-sweep workgroup per channel; 3: one
     // one-sweep workgroup per channel (an independent implementation of the same chase, kept as the cross-check of
     // tests/test_gpu_solve.py::test_sb2st_fallback_paths); v1, v2, v4, v6 are in the history only
+    // 9: the two-step route of sbr2.hip (band 64 -> 16 -> 1)
+    if (ver == 9) {
+        int rc;
+        if ((rc = launch_sb2sb(n, npad, batch, d_AB, st))) return rc;
+        return launch_sb16st(n, npad, batch, d_AB, d_d, d_e, st);
+    }
     if (ver != 3 && ver != 7 && ver != 8) return BSP_ERR_ARG;
     if (ver == 7 || ver == 8) {
         // 7: one workgroup per channel; 8: two (the partner CU runs the two sweeps in between), v6's pairing

@@ -1,0 +1,456 @@
+// sbr2.hip -- the bulge chasing in TWO steps (BSP_SB2ST_VERSION=9): band 64 -> band 16 -> tridiagonal.
+//
+// Replaces DSYTRD's second half inside DSYGV (reference call site matrices.f90:248) like sb2st.hip does; the reason for a
+// second route is bytes: a one-column-at-a-time chase of a band of half-width b re-reads and re-writes the band once per
+// sweep (or per two sweeps, sb2st.hip v7/v8): 6 n^2 b bytes per channel, 825 GB per 128-channel step at b = 64.  Here
+//   step 1 (sb2sb_kernel): BLOCK bulge chasing (Bischof/Lang/Sun's SBR scheme).  A sweep takes 16 columns at once: QR of a
+//          64 x 16 block, the block reflector Q = I - V T V^T applied to three 64 x 64 tiles per chase item -- the same tiles a
+//          column sweep touches, 16 times less often.  Items (sweep s, step k) with k + 3 s = t are independent (their tile
+//          sets are disjoint, tools/proto_sbr.py checks it), so ONE LAUNCH PER WAVEFRONT t orders everything: no flags, no
+//          spinning, bit-identical results by construction.
+//   step 2 (sb16st_kernel): one-column chase of the band of half-width 16, ONE workgroup per channel: its 8 waves run 8
+//          consecutive sweeps, three items apart, on a sliding window of the band held in LDS (512 columns x 32 rows:
+//          the band and what the sweeps leave of their bulges, which stays in the matrix between passes);
+//          HBM sees each pass of 8 sweeps once.
+// Index conventions, the lag of 3 and the working band (<= 127 / <= 31 sub-diagonals) are those of tools/proto_sbr.py.
+// Band storage as everywhere: AB[d + 128 j] = A(j + d, j) (sy2sb.hip::extract_band_kernel).
+#include "common.h"
+#include <cstdio>
+
+namespace bsp {
+namespace {
+
+constexpr int LD = 128;
+constexpr int B1 = 64, NB1 = 16, LAG = 3;
+constexpr int XLD = 65, VLD = 17;
+constexpr int SB2SB_LDS = (64 * XLD + 3 * 64 * VLD + 16 * XLD + 2 * 16 * VLD + 16) * 8;
+
+__device__ __forceinline__ double wsum64(double v)
+{
+    for (int m = 32; m; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// One chase item of the block scheme.  256 threads; lane = row of the tile, wave = column group.
+__global__ __launch_bounds__(256) void sb2sb_kernel(int n, int npad, double *__restrict__ ABall, int t, int s_lo)
+{
+    extern __shared__ double lds[];
+    double *X = lds, *V = X + 64 * XLD, *Y = V + 64 * VLD, *Z = Y + 64 * VLD, *W = Z + 64 * VLD, *T = W + 16 * XLD,
+           *G = T + 16 * VLD, *tau = G + 16 * VLD;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int s = s_lo + blockIdx.x, k = t - LAG * s;
+    if (k < 0) return;
+    const int j0 = NB1 * s, r0 = j0 + NB1 + B1 * k;
+    if (r0 >= n) return;
+    double *AB = ABall + blockIdx.y * ab_stride(npad);
+    const int pc0 = k == 0 ? j0 : r0 - B1;               // first column of the left tile (the panel)
+    const int ncl = k == 0 ? NB1 : B1;
+    const int gi = r0 + lane;                            // this lane's row
+
+    // ---- left tile: rows r0.., columns pc0 .. pc0+ncl
+    for (int c = wv; c < ncl; c += 4) {
+        const int gc = pc0 + c;
+        X[c * XLD + lane] = gi < n ? AB[(size_t)gc * LD + (gi - gc)] : 0.0;
+    }
+    __syncthreads();
+    // Householder QR of its first 16 columns; V explicit (unit diagonal, zeros above), R left in X
+    for (int i = 0; i < NB1; ++i) {
+        if (wv == 0) {
+            const double x = X[i * XLD + lane];
+            const double nrm2 = wsum64(lane > i ? x * x : 0.0);
+            const double alpha = X[i * XLD + i];
+            double tq = 0.0, scale = 0.0, beta = alpha;
+            if (nrm2 != 0.0) {
+                beta = -copysign(sqrt(alpha * alpha + nrm2), alpha);
+                tq = (beta - alpha) / beta;
+                scale = 1.0 / (alpha - beta);
+            }
+            V[lane * VLD + i] = lane < i ? 0.0 : (lane == i ? 1.0 : x * scale);
+            if (lane == 0) tau[i] = tq;
+            X[i * XLD + lane] = lane < i ? x : (lane == i ? beta : 0.0);
+        }
+        __syncthreads();
+        const double tq = tau[i];
+        for (int j = i + 1 + wv; j < NB1; j += 4) {
+            const double v = V[lane * VLD + i], x = X[j * XLD + lane];
+            const double dot = wsum64(v * x);
+            X[j * XLD + lane] = x - tq * dot * v;
+        }
+        __syncthreads();
+    }
+    // T of Q = H_1 .. H_16 = I - V T V^T (forward, columnwise)
+    {
+        const int i = tid >> 4, j = tid & 15;
+        double a = 0.0;
+        for (int r = 0; r < 64; ++r) a += V[r * VLD + i] * V[r * VLD + j];
+        G[i * VLD + j] = a;
+        T[i * VLD + j] = 0.0;
+    }
+    __syncthreads();
+    for (int i = 0; i < NB1; ++i) {
+        if (tid < i) {
+            double a = 0.0;
+            for (int m = tid; m < i; ++m) a += T[tid * VLD + m] * G[m * VLD + i];
+            T[tid * VLD + i] = -tau[i] * a;
+        }
+        if (tid == i) T[i * VLD + i] = tau[i];
+        __syncthreads();
+    }
+    if (k > 0) {                                         // X(:, 16:64) <- Q^T X = X - V (T^T (V^T X))
+        const int i = tid & 15, c = 16 + (tid >> 4) * 3;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int r = 0; r < 64; ++r) {
+            const double v = V[r * VLD + i];
+            a0 += v * X[c * XLD + r]; a1 += v * X[(c + 1) * XLD + r]; a2 += v * X[(c + 2) * XLD + r];
+        }
+        W[i * XLD + c] = a0; W[i * XLD + c + 1] = a1; W[i * XLD + c + 2] = a2;
+        __syncthreads();
+        double b0 = 0.0, b1 = 0.0, b2 = 0.0;
+        for (int j = 0; j <= i; ++j) {
+            const double tj = T[j * VLD + i];
+            b0 += tj * W[j * XLD + c]; b1 += tj * W[j * XLD + c + 1]; b2 += tj * W[j * XLD + c + 2];
+        }
+        __syncthreads();
+        W[i * XLD + c] = b0; W[i * XLD + c + 1] = b1; W[i * XLD + c + 2] = b2;
+        __syncthreads();
+        double vr[16];
+        for (int q = 0; q < 16; ++q) vr[q] = V[lane * VLD + q];
+        for (int cc = 16 + wv * 12; cc < 16 + wv * 12 + 12; ++cc) {
+            double a = X[cc * XLD + lane];
+            for (int q = 0; q < 16; ++q) a -= vr[q] * W[q * XLD + cc];
+            X[cc * XLD + lane] = a;
+        }
+        __syncthreads();
+    }
+    for (int c = wv; c < ncl; c += 4) {
+        const int gc = pc0 + c;
+        if (gi < n) AB[(size_t)gc * LD + (gi - gc)] = X[c * XLD + lane];
+    }
+    __syncthreads();
+
+    // ---- diagonal tile: D <- Q^T D Q = D - V Z^T - Z V^T,  Y = D V T,  Z = Y - 1/2 V (T^T V^T Y)
+    for (int c = wv; c < 64; c += 4) {
+        if (lane >= c) {
+            const double v = gi < n ? AB[(size_t)(r0 + c) * LD + (lane - c)] : 0.0;
+            X[c * XLD + lane] = v;
+            X[lane * XLD + c] = v;
+        }
+    }
+    __syncthreads();
+    {
+        double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+        for (int c = 0; c < 64; ++c) {
+            const double d = X[c * XLD + lane];
+            const double *vc = V + c * VLD + 4 * wv;
+            y0 += d * vc[0]; y1 += d * vc[1]; y2 += d * vc[2]; y3 += d * vc[3];
+        }
+        double *yr = Y + lane * VLD + 4 * wv;
+        yr[0] = y0; yr[1] = y1; yr[2] = y2; yr[3] = y3;
+    }
+    __syncthreads();
+    for (int q = 0; q < 4; ++q) {
+        const int i = 4 * wv + q;
+        double a = 0.0;
+        for (int m = 0; m <= i; ++m) a += Y[lane * VLD + m] * T[m * VLD + i];
+        Z[lane * VLD + i] = a;
+    }
+    __syncthreads();
+    {
+        const int i = tid >> 4, j = tid & 15;
+        double a = 0.0;
+        for (int r = 0; r < 64; ++r) a += V[r * VLD + i] * Z[r * VLD + j];
+        G[i * VLD + j] = a;
+    }
+    __syncthreads();
+    {
+        const int i = tid >> 4, j = tid & 15;
+        double a = 0.0;
+        for (int m = 0; m <= i; ++m) a += T[m * VLD + i] * G[m * VLD + j];
+        W[i * XLD + j] = a;                              // M = T^T V^T Y (symmetric)
+    }
+    __syncthreads();
+    for (int q = 0; q < 4; ++q) {
+        const int i = 4 * wv + q;
+        double a = 0.0;
+        for (int m = 0; m < 16; ++m) a += V[lane * VLD + m] * W[m * XLD + i];
+        Z[lane * VLD + i] -= 0.5 * a;
+    }
+    __syncthreads();
+    {
+        double vr[16], zr[16];
+        for (int q = 0; q < 16; ++q) { vr[q] = V[lane * VLD + q]; zr[q] = Z[lane * VLD + q]; }
+        for (int c = 16 * wv; c < 16 * wv + 16; ++c) {
+            if (lane >= c) {
+                double a = X[c * XLD + lane];
+                for (int q = 0; q < 16; ++q) a -= vr[q] * Z[c * VLD + q] + zr[q] * V[c * VLD + q];
+                if (gi < n) AB[(size_t)(r0 + c) * LD + (lane - c)] = a;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- next bulge tile: X' <- X' Q = X' - (X' V T) V^T, rows r0+64.., columns r0..
+    const int r1 = r0 + B1;
+    if (r1 >= n) return;
+    const int gi1 = r1 + lane;
+    for (int c = wv; c < 64; c += 4) {
+        const int gc = r0 + c;
+        X[c * XLD + lane] = gi1 < n ? AB[(size_t)gc * LD + (gi1 - gc)] : 0.0;
+    }
+    __syncthreads();
+    {
+        double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+        for (int c = 0; c < 64; ++c) {
+            const double d = X[c * XLD + lane];
+            const double *vc = V + c * VLD + 4 * wv;
+            y0 += d * vc[0]; y1 += d * vc[1]; y2 += d * vc[2]; y3 += d * vc[3];
+        }
+        double *yr = Y + lane * VLD + 4 * wv;
+        yr[0] = y0; yr[1] = y1; yr[2] = y2; yr[3] = y3;
+    }
+    __syncthreads();
+    for (int q = 0; q < 4; ++q) {
+        const int i = 4 * wv + q;
+        double a = 0.0;
+        for (int m = 0; m <= i; ++m) a += Y[lane * VLD + m] * T[m * VLD + i];
+        Z[lane * VLD + i] = a;
+    }
+    __syncthreads();
+    {
+        double zr[16];
+        for (int q = 0; q < 16; ++q) zr[q] = Z[lane * VLD + q];
+        for (int c = 16 * wv; c < 16 * wv + 16; ++c) {
+            double a = X[c * XLD + lane];
+            for (int q = 0; q < 16; ++q) a -= zr[q] * V[c * VLD + q];
+            if (gi1 < n) AB[(size_t)(r0 + c) * LD + (gi1 - (r0 + c))] = a;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// step 2: band 16 -> tridiagonal.  One workgroup (8 waves) per channel.  Wave w of pass p runs sweep s = 8 p + w; at step t it
+// works on item k = t - 3 w of its sweep.  A 16 x 16 tile lives in a wave as 4 doubles per lane: lane = (row r = lane & 15,
+// column group g = lane >> 4, columns 4 g .. 4 g + 3).
+constexpr int B2 = 16, NW2 = 8, WCOLS = 512, WROWS = 32;
+constexpr int SB16_LDS = (WCOLS * WROWS + NW2 * 16) * 8;
+
+template <int CTRL>
+__device__ __forceinline__ double dppd(double x)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, 0xf, 0xf, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, 0xf, 0xf, true);
+    return r.d;
+}
+__device__ __forceinline__ double rdlane(double x, int l)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_readlane(u.i[0], l);
+    r.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+    return r.d;
+}
+// Sum over the 16 lanes of a DPP row, the total in every lane (bitwise the same in all of them: each step adds the two
+// halves of a pair, and addition commutes): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror.
+__device__ __forceinline__ double rsum16(double x)
+{
+    x += dppd<0xB1>(x);
+    x += dppd<0x4E>(x);
+    x += dppd<0x141>(x);
+    x += dppd<0x140>(x);
+    return x;
+}
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(576) void sb16st_kernel(int n, int npad, double *__restrict__ ABall, double *__restrict__ dall,
+                                                     double *__restrict__ eall, long long *diag)
+{
+    extern __shared__ double lds[];
+    double *Lw = lds;
+    long long dacc[5] = {0, 0, 0, 0, 0}, dt0 = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    double *pS = lds + WCOLS * WROWS + (wv & 7) * 16;
+    double *AB = ABall + blockIdx.x * ab_stride(npad);
+#define LW(i, c) Lw[((((c)) & (WCOLS - 1)) << 5) + ((i) - (c))]
+
+    double *dump = AB + (size_t)npad * LD + 64;              // padding behind the band (ab_stride): target of masked stores
+    for (int s0 = 0; s0 < n - 2; s0 += NW2) {
+        int RP = s0, LP = s0 + 64;
+        for (int idx = tid; idx < 64 * WROWS; idx += 576) {
+            const int c = s0 + (idx >> 5), d = idx & 31;
+            Lw[((c & (WCOLS - 1)) << 5) + d] = c + d < n ? AB[(size_t)c * LD + d] : 0.0;
+        }
+        // Wave 8 moves data and does nothing else.  Columns enter the window in blocks of 64 every fourth step, four steps
+        // after their loads were issued (the registers are not touched in between, so nothing waits for HBM); columns
+        // leave it with plain stores, 16 per step.  The eight chasing waves never touch global memory inside a pass.
+        const int md = lane & 31, mh = lane >> 5;                   // mover lane: row md of columns 2 i + mh
+        double qb[32];
+        if (wv == NW2) {
+            for (int i = 0; i < 32; ++i) {                          // unmasked value; the mask is applied at the LDS write
+                const int c = LP + 2 * i + mh;
+                qb[i] = AB[c + md < n ? (size_t)c * LD + md : 0];
+            }
+        }
+        __syncthreads();
+        const int s = s0 + wv;
+        const int nsteps = (n - s0 - 1 + B2 - 1) / B2 + LAG * (NW2 - 1);
+        for (int t = 0; t < nsteps; ++t) {
+            int RPn = s0 + NW2 + B2 * (t - LAG * (NW2 - 1) - 1);           // columns leaving: left of the trailing wave's tiles
+            if (RPn > n) RPn = n;
+            if (RPn < RP) RPn = RP;
+            if (wv == NW2) {
+                for (int i = 0; i < 8; ++i) {
+                    const int c = RP + 2 * i + mh;
+                    double *gp = c < RPn ? AB + (size_t)c * LD + md : dump + lane;
+                    *gp = Lw[((c & (WCOLS - 1)) << 5) + md];
+                }
+                if ((t & 3) == 0) {
+                    for (int i = 0; i < 32; ++i) {
+                        const int c = LP + 2 * i + mh;
+                        Lw[((c & (WCOLS - 1)) << 5) + md] = c + md < n ? qb[i] : 0.0;
+                    }
+                    for (int i = 0; i < 32; ++i) {
+                        const int c = LP + 64 + 2 * i + mh;
+                        qb[i] = AB[c + md < n ? (size_t)c * LD + md : 0];
+                    }
+                }
+            }
+            if ((t & 3) == 0) LP += 64;
+            RP = RPn;
+            const int k = t - LAG * wv;
+            const int r0 = s + 1 + B2 * k;
+            if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime();
+            if (wv < NW2 && k >= 0 && s < n - 2 && r0 < n) {
+                const int c0 = k == 0 ? s : r0 - B2;
+                const int r1 = r0 + B2;
+                // everything the item reads, requested at once.  Layouts: B and D tiles lane = (row r, columns 4g..4g+3);
+                // the next bulge tile transposed, lane = (column r, rows 4g..4g+3): every reduction stays inside a DPP row
+                const double x = LW(r0 + r, c0);
+                double xc[4], b[4], dv[4], bt[4];
+                for (int j = 0; j < 4; ++j) {
+                    const int cc = 4 * g + j;
+                    xc[j] = LW(r0 + cc, c0);
+                    b[j] = k > 0 ? LW(r0 + r, c0 + cc) : 0.0;
+                    dv[j] = r >= cc ? LW(r0 + r, r0 + cc) : LW(r0 + cc, r0 + r);
+                    bt[j] = LW(r1 + cc, r0 + r);
+                }
+                if (diag) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[0] += t_ - dt0; dt0 = t_; }
+                const double nrm2 = rsum16(r > 0 ? x * x : 0.0);
+                const double alpha = rdlane(x, 0);
+                double tq = 0.0, scale = 0.0, beta = alpha;
+                if (nrm2 != 0.0) {
+                    beta = -copysign(sqrt(alpha * alpha + nrm2), alpha);
+                    tq = (beta - alpha) / beta;
+                    scale = 1.0 / (alpha - beta);
+                }
+                const double v = r == 0 ? 1.0 : x * scale;
+                double vc[4];
+                for (int j = 0; j < 4; ++j) vc[j] = (4 * g + j) == 0 ? 1.0 : xc[j] * scale;
+                if (g == 0) LW(r0 + r, c0) = r == 0 ? beta : 0.0;
+                if (diag) { asm volatile("" :: "v"(v)); const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[1] += t_ - dt0; dt0 = t_; }
+                // rest of the bulge tile: B <- H B
+                if (k > 0) {
+                    for (int j = 0; j < 4; ++j) {
+                        const double dot = rsum16(v * b[j]);
+                        if (4 * g + j > 0) LW(r0 + r, c0 + 4 * g + j) = b[j] - tq * dot * v;
+                    }
+                }
+                // next bulge tile: B' <- B' H (transposed layout: the row sums are sums over a DPP row)
+                for (int j = 0; j < 4; ++j) {
+                    const double q = tq * rsum16(bt[j] * v);
+                    LW(r1 + 4 * g + j, r0 + r) = bt[j] - q * v;
+                }
+                // diagonal tile, two-sided: p = tau D v by columns (D is symmetric), by rows through pS
+                double pc[4], part = 0.0;
+                for (int j = 0; j < 4; ++j) {
+                    pc[j] = tq * rsum16(v * dv[j]);
+                    part += vc[j] * pc[j];
+                }
+                if (r < 4) pS[4 * g + r] = r == 0 ? pc[0] : (r == 1 ? pc[1] : (r == 2 ? pc[2] : pc[3]));
+                const double vtp = (rdlane(part, 0) + rdlane(part, 16)) + (rdlane(part, 32) + rdlane(part, 48));
+                const double kk = 0.5 * tq * vtp;
+                const double w = pS[r] - kk * v;
+                for (int j = 0; j < 4; ++j) {
+                    const int cc = 4 * g + j;
+                    const double wc = pc[j] - kk * vc[j];
+                    if (r >= cc) LW(r0 + r, r0 + cc) = dv[j] - v * wc - w * vc[j];
+                }
+                if (diag) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[2] += t_ - dt0; dt0 = t_; }
+            }
+            lds_only_barrier();
+            if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; }
+        }
+        __syncthreads();
+        int hi = LP < n ? LP : n;
+        for (int idx = tid; idx < (hi - RP) * WROWS; idx += 576) {
+            const int c = RP + (idx >> 5), d = idx & 31;
+            AB[(size_t)c * LD + d] = Lw[((c & (WCOLS - 1)) << 5) + d];
+        }
+        __syncthreads();
+    }
+#undef LW
+    if (diag && blockIdx.x == 0 && lane == 0)
+        for (int q = 0; q < 5; ++q) diag[wv * 5 + q] = dacc[q];
+    double *dd = dall + blockIdx.x * (size_t)npad, *ee = eall + blockIdx.x * (size_t)npad;
+    for (int j = tid; j < n; j += 576) {
+        dd[j] = AB[(size_t)j * LD];
+        ee[j] = j < n - 1 ? AB[(size_t)j * LD + 1] : 0.0;
+    }
+}
+
+}  // namespace
+
+int launch_sb2sb(int n, int npad, int batch, double *d_AB, hipStream_t st)
+{
+    static bool attr = false;
+    if (!attr) {
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sb2sb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    SB2SB_LDS));
+        attr = true;
+    }
+    const int S = (n - NB1 + NB1 - 1) / NB1;                       // sweeps: j0 + 16 < n
+    auto K = [n](int s) { const int m = n - (NB1 * s + NB1); return m > 0 ? (m + B1 - 1) / B1 : 0; };
+    int tmax = -1;
+    for (int s = 0; s < S; ++s)
+        if (K(s) > 0 && K(s) - 1 + LAG * s > tmax) tmax = K(s) - 1 + LAG * s;
+    for (int t = 0; t <= tmax; ++t) {
+        int s_hi = t / LAG;
+        if (s_hi > S - 1) s_hi = S - 1;
+        if (t - LAG * s_hi >= K(s_hi)) continue;
+        int s_lo = s_hi;
+        while (s_lo > 0 && t - LAG * (s_lo - 1) < K(s_lo - 1)) --s_lo;
+        hipLaunchKernelGGL(sb2sb_kernel, dim3(s_hi - s_lo + 1, batch), dim3(256), SB2SB_LDS, st, n, npad, d_AB, t, s_lo);
+    }
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
+
+int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st)
+{
+    static bool attr = false;
+    if (!attr) {
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sb16st_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    SB16_LDS));
+        attr = true;
+    }
+    if (opts().sb2st_diag) {                                // cycles per phase of the chasing waves (workgroup 0)
+        long long *dbuf = nullptr, h[45];
+        BSP_HIP(hipMalloc(reinterpret_cast<void **>(&dbuf), sizeof(h)));
+        hipLaunchKernelGGL(sb16st_kernel, dim3(batch), dim3(576), SB16_LDS, st, n, npad, d_AB, d_d, d_e, dbuf);
+        BSP_HIP(hipStreamSynchronize(st));
+        BSP_HIP(hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost));
+        hipFree(dbuf);
+        for (int w = 0; w < 9; ++w)
+            fprintf(stderr, "sb16st wave %d: steps %lld; cycles per step (100 MHz ticks x 24): tile loads %.0f, reflector %.0f, products + stores %.0f, rest + barrier %.0f\n",
+                    w, h[w * 5 + 4], 24.0 * h[w * 5] / h[w * 5 + 4], 24.0 * h[w * 5 + 1] / h[w * 5 + 4], 24.0 * h[w * 5 + 2] / h[w * 5 + 4],
+                    24.0 * h[w * 5 + 3] / h[w * 5 + 4]);
+        return BSP_OK;
+    }
+    hipLaunchKernelGGL(sb16st_kernel, dim3(batch), dim3(576), SB16_LDS, st, n, npad, d_AB, d_d, d_e, (long long *)nullptr);
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
+
+}  // namespace bsp

@@ -145,6 +145,8 @@ int bspatom_stage_standard_form(int n, int k, int nl, const double *SB, const do
 int bspatom_stage_sy2sb(int npad, int batch, const double *A, double *AB);
 /* band (AB as above, leading n x n) -> tridiagonal d[n], e[n-1] (ld npad) */
 int bspatom_stage_sb2st(int n, int npad, int batch, const double *AB, double *d, double *e);
+/* first half of the two-step route (sb2st_version 9): band 64 -> band 16 in place, same layout */
+int bspatom_stage_sb2sb(int n, int npad, int batch, double *AB);
 /* eigenvalues of tridiagonal matrices, ascending */
 int bspatom_stage_bisect(int n, int batch, const double *d, const double *e, double *w);
 

@@ -530,6 +530,29 @@ def test_sb2st_fallback_paths():
     prob.close()
 
 
+def test_two_step_band_reduction_route():
+    """sb2st_version 9 (csrc/sbr2.hip: band 64 -> 16 by block bulge chasing, 16 -> tridiagonal in an LDS window; experimental, not
+    the default): the whole solve on C2 (n = 2048) against the reference spectrum and the truth, same bar as the default route;
+    12 channels at n = 1024 against the default route to rounding, and bit-identical when repeated."""
+    prob = capi.Problem(input_from_case("c2_2048"))
+    with _Options(sb2st_version=9):
+        E, info = prob.solve(0, 1)
+    assert np.all(info == 0)
+    g = load_golden("c2_2048")
+    full_size_bar(E[0], g["E"][0], "sb2st_version=9 c2_2048", load_truth("c2_2048")[0])
+    prob.close()
+    prob = capi.Problem(input_from_case("c3_1024_l31"))
+    E0, info = prob.solve(0, 12)
+    with _Options(sb2st_version=9):
+        E1, info1 = prob.solve(0, 12)
+        E2, info2 = prob.solve(0, 12)
+    assert np.all(info1 == 0) and np.array_equal(E1, E2)
+    lam = np.max(np.abs(E0))
+    note("sb2st version 9 vs default, 12 channels n=1024: normwise %.2e" % (np.max(np.abs(E1 - E0)) / lam))
+    assert np.max(np.abs(E1 - E0)) <= 1e-13 * lam
+    prob.close()
+
+
 def test_panel_qr_first_kernel_matches_second():
     """panel_qr_kernel (the first panel kernel) serves every panel above 4096 rows; forced for ALL panels at n = 2048
     it must reproduce the spectra of the LDS-DMA kernel to rounding (they order the reductions differently)."""

@@ -137,6 +137,7 @@ def test_standard_form(name):
 def _band_eigs(AB, n, b=64):
     import scipy.linalg as sla
     # AB[j, d] = A(j+d, j): lower band form for scipy (rows = diagonals)
+    b = min(b, n - 1)
     ab = np.zeros((b + 1, n))
     for d in range(b + 1):
         ab[d, :n - d] = AB[:n - d, d]
@@ -175,6 +176,53 @@ def test_sb2st(n, npad, batch):
         ev = eigvalsh_tridiagonal(d[b], e[b])
         err = np.max(np.abs(ev - ref)) / np.max(np.abs(ref))
         note("sb2st n %d b%d eig err %.2e" % (n, b, err))
+        assert err < 5e-14 * np.sqrt(n)
+
+
+def _random_band64(n, npad, batch, seed):
+    rng = np.random.default_rng(seed)
+    AB = np.zeros((batch, npad, 128))
+    for b in range(batch):
+        for j in range(n):
+            m = min(64, n - 1 - j)
+            AB[b, j, :m + 1] = rng.standard_normal(m + 1) * np.exp(-0.05 * np.arange(m + 1) * b)
+    return AB
+
+
+@pytest.mark.parametrize("n,npad,batch", [(100, 128, 1), (448, 448, 2), (1000, 1024, 2), (2048, 2048, 1)])
+def test_sb2sb_to_band16(n, npad, batch):
+    """Step 1 of the two-step route (csrc/sbr2.hip, tools/proto_sbr.py): block bulge chasing 64 -> 16.  The result has no
+    entry beyond sub-diagonal 16 (exact zeros: they are stored as such) and the eigenvalues of the input."""
+    AB = _random_band64(n, npad, batch, n)
+    out = capi.stage_sb2sb(AB, n)
+    for b in range(batch):
+        ref = _band_eigs(AB[b], n)
+        ev = _band_eigs(out[b], n, 16)
+        err = np.max(np.abs(ev - ref)) / np.max(np.abs(ref))
+        beyond = np.max(np.abs(out[b][:n, 17:]))
+        note("sb2sb n %d b%d eig err %.2e  max |entry beyond 16| %.1e" % (n, b, err, beyond))
+        assert beyond <= 1e-13 * np.max(np.abs(ref))
+        assert err < 5e-14 * np.sqrt(n)
+
+
+@pytest.mark.parametrize("n,npad,batch", [(40, 64, 1), (100, 128, 1), (448, 448, 2), (1000, 1024, 2), (2048, 2048, 1)])
+def test_sb2st_two_step(n, npad, batch):
+    """Both steps (sb2st_version 9): band 64 -> 16 -> tridiagonal, eigenvalues of the input; bit-identical when repeated."""
+    from scipy.linalg import eigvalsh_tridiagonal
+    AB = _random_band64(n, npad, batch, 7 * n)
+    old = capi.get_option("sb2st_version")
+    capi.set_option("sb2st_version", 9)
+    try:
+        d, e = capi.stage_sb2st(AB, n)
+        d2, e2 = capi.stage_sb2st(AB, n)
+    finally:
+        capi.set_option("sb2st_version", old)
+    assert np.array_equal(d, d2) and np.array_equal(e, e2)
+    for b in range(batch):
+        ref = _band_eigs(AB[b], n)
+        ev = eigvalsh_tridiagonal(d[b], e[b])
+        err = np.max(np.abs(ev - ref)) / np.max(np.abs(ref))
+        note("sb2st two-step n %d b%d eig err %.2e" % (n, b, err))
         assert err < 5e-14 * np.sqrt(n)
 
 
