@@ -56,7 +56,7 @@ const OptName OPT_TABLE[] = {
     {"gemm_diag", "BSP_GEMM_DIAG", &Options::gemm_diag}, {"bisect", "BSP_BISECT", &Options::bisect},
     {"bisect_ept", "BSP_BISECT_EPT", &Options::bisect_ept},
     {"bisect_tail", "BSP_BISECT_TAIL", &Options::bisect_tail}, {"no_eigvec_prefetch", "BSP_NO_EIGVEC_PREFETCH", &Options::no_eigvec_prefetch},
-    {"poison_c", "BSP_POISON_C", &Options::poison_c},
+    {"poison_c", "BSP_POISON_C", &Options::poison_c}, {"sb2sb_mfma", "BSP_SB2SB_MFMA", &Options::sb2sb_mfma},
 };
 }  // namespace
 

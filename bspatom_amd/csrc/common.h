@@ -50,6 +50,7 @@ struct Options {
     int bisect = 3, bisect_ept = 0;
     int bisect_tail = 1;         // BSP_BISECT_TAIL: 0 = lock-step bisection to the end (no multisection tail), for A/B timing
     int no_eigvec_prefetch = 0;
+    int sb2sb_mfma = 1;          // 1: block-chasing item on the matrix cores (sbr2.hip); 0: the first, all-VALU kernel (cross-check)
     int poison_c = 0;            // test hook: fill the dense C buffer with NaN bit patterns before every solve (nothing outside the
                                  // blocks the standard form writes may ever be read)
 };

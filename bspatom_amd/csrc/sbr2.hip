@@ -228,6 +228,242 @@ __global__ __launch_bounds__(256) void sb2sb_kernel(int n, int npad, double *__r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The same item on the matrix cores.  Every product has a 16 in one dimension, the shape of v_mfma_f64_16x16x4:
+//   a = A[m = lane & 15][k = lane >> 4],  b = B[k = lane >> 4][n = lane & 15],  acc[r] = C[m = (lane >> 4) + 4 r][n = lane & 15]
+// (layouts as in gemm_f64.hip).  With VT = V T (from T^-1 = striu(V^T V) + diag(1/tau) by forward substitution, T itself is
+// never formed):  left tile X <- X - V (VT^T X);  diagonal tile Y = D VT, M = VT^T Y, Z = Y - 1/2 V M, D <- D - V Z^T - Z V^T;
+// next tile X' <- X' - (X' VT) V^T.  The QR keeps the panel in registers (wave w owns columns w, w+4, w+8, w+12), one
+// LDS-only barrier per column, wave sums by DPP row scans.
+typedef double d4_t __attribute__((ext_vector_type(4)));
+constexpr int SB2SB2_LDS = (64 * XLD + 4 * 64 * VLD + 16 * VLD + 16) * 8;
+
+template <int CTRL>
+__device__ __forceinline__ double dppm(double x)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, 0xf, 0xf, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, 0xf, 0xf, true);
+    return r.d;
+}
+__device__ __forceinline__ double rlane(double x, int l)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_readlane(u.i[0], l);
+    r.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+    return r.d;
+}
+__device__ __forceinline__ double wsum_dpp(double x)          // uniform result: row scans + the four row totals
+{
+    x += dppm<0x111>(x); x += dppm<0x112>(x); x += dppm<0x114>(x); x += dppm<0x118>(x);
+    return (rlane(x, 15) + rlane(x, 31)) + (rlane(x, 47) + rlane(x, 63));
+}
+__device__ __forceinline__ void lds_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+__global__ __launch_bounds__(256) void sb2sb_mfma_kernel(int n, int npad, double *__restrict__ ABall, int t, int s_lo)
+{
+    extern __shared__ double lds[];
+    double *X = lds, *V = X + 64 * XLD, *VT = V + 64 * VLD, *Yb = VT + 64 * VLD, *Z = Yb + 64 * VLD, *G = Z + 64 * VLD,
+           *tau = G + 16 * VLD;
+    double *Gp = Z;                                       // split-K partials [4][16 x VLD] live where Z is not yet
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int s = s_lo + blockIdx.x, k = t - LAG * s;
+    if (k < 0) return;
+    const int j0 = NB1 * s, r0 = j0 + NB1 + B1 * k;
+    if (r0 >= n) return;
+    double *AB = ABall + blockIdx.y * ab_stride(npad);
+    const int pc0 = k == 0 ? j0 : r0 - B1;
+    const int ncl = k == 0 ? NB1 : B1;
+    const int gi = r0 + lane;
+
+    // ---- panel into registers (and the rest of the left tile into X)
+    double xc[4];
+    for (int q = 0; q < 4; ++q) {
+        const int gc = pc0 + w + 4 * q;
+        xc[q] = gi < n ? AB[(size_t)gc * LD + (gi - gc)] : 0.0;
+    }
+    if (k > 0)
+        for (int c = 16 + w; c < 64; c += 4) {
+            const int gc = pc0 + c;
+            X[c * XLD + lane] = gi < n ? AB[(size_t)gc * LD + (gi - gc)] : 0.0;
+        }
+    // the diagonal tile is requested now and waited for after the QR; the next bulge tile before the diagonal tile's products
+    double pf[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = w + 4 * q;                          // column c, rows lane >= c (clamped address, masked at use)
+        const bool in = lane >= c && gi < n;
+        pf[q] = AB[in ? (size_t)(r0 + c) * LD + (lane - c) : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < NB1; ++i) {
+        if (w == (i & 3)) {
+            const double x = xc[i >> 2];
+            const double nrm2 = wsum_dpp(lane > i ? x * x : 0.0);
+            const double alpha = rlane(x, i);
+            double tq = 0.0, scale = 0.0, beta = alpha;
+            if (nrm2 != 0.0) {
+                beta = -copysign(sqrt(alpha * alpha + nrm2), alpha);
+                tq = (beta - alpha) / beta;
+                scale = 1.0 / (alpha - beta);
+            }
+            V[lane * VLD + i] = lane < i ? 0.0 : (lane == i ? 1.0 : x * scale);
+            if (lane == 0) tau[i] = tq;
+            xc[i >> 2] = lane < i ? x : (lane == i ? beta : 0.0);
+        }
+        lds_bar();
+        const double v = V[lane * VLD + i], tq = tau[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (w + 4 * q > i) {
+                const double dot = wsum_dpp(v * xc[q]);
+                xc[q] -= tq * dot * v;
+            }
+    }
+    for (int q = 0; q < 4; ++q) {                          // R (and zeros) back to the band
+        const int gc = pc0 + w + 4 * q;
+        if (gi < n) AB[(size_t)gc * LD + (gi - gc)] = xc[q];
+    }
+    // G = V^T V, split over the waves along the rows
+    {
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < 4; ++q) {
+            const double a = V[(16 * w + 4 * q + l4) * VLD + l15];
+            acc = MFMA(a, a, acc);
+        }
+        for (int r = 0; r < 4; ++r) Gp[w * 16 * VLD + (l4 + 4 * r) * VLD + l15] = acc[r];
+    }
+    lds_bar();
+    {
+        const int i = tid >> 4, j = tid & 15, o = i * VLD + j;
+        G[o] = (Gp[o] + Gp[16 * VLD + o]) + (Gp[32 * VLD + o] + Gp[48 * VLD + o]);
+    }
+    lds_bar();
+    if (w == 0) {                                         // VT T^-1 = V, row by row
+        double vt[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            double a = V[lane * VLD + j];
+#pragma unroll
+            for (int i = 0; i < j; ++i) a -= vt[i] * G[i * VLD + j];
+            vt[j] = a * tau[j];
+            VT[lane * VLD + j] = vt[j];
+        }
+    }
+    lds_bar();
+
+    // ---- left tile
+    if (k > 0) {
+        if (w < 3) {                                      // W2 = VT^T X(:, 16:64), block w
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+            const int cn = 16 + 16 * w + l15;
+            for (int q = 0; q < 16; ++q) acc = MFMA(VT[(4 * q + l4) * VLD + l15], X[cn * XLD + 4 * q + l4], acc);
+            for (int r = 0; r < 4; ++r) Yb[(l4 + 4 * r) * XLD + cn] = acc[r];
+        }
+        lds_bar();
+        for (int nb = 0; nb < 3; ++nb) {                  // X(:, 16:64) -= V W2, row block w
+            const int cn = 16 + 16 * nb + l15;
+            d4_t acc;
+            for (int r = 0; r < 4; ++r) acc[r] = X[cn * XLD + 16 * w + l4 + 4 * r];
+            for (int q = 0; q < 4; ++q) acc = MFMA(-V[(16 * w + l15) * VLD + 4 * q + l4], Yb[(4 * q + l4) * XLD + cn], acc);
+            for (int r = 0; r < 4; ++r) X[cn * XLD + 16 * w + l4 + 4 * r] = acc[r];
+        }
+        lds_bar();
+        for (int c = 16 + w; c < 64; c += 4) {
+            const int gc = pc0 + c;
+            if (gi < n) AB[(size_t)gc * LD + (gi - gc)] = X[c * XLD + lane];
+        }
+        lds_bar();
+    }
+
+    // ---- diagonal tile
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = w + 4 * q;
+        if (lane >= c) {
+            const double v = gi < n ? pf[q] : 0.0;
+            X[c * XLD + lane] = v;
+            X[lane * XLD + c] = v;
+        }
+    }
+    const int r1 = r0 + B1, gi1 = r1 + lane;
+    const bool more = r1 < n;
+    if (more) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int gc = r0 + w + 4 * q;
+            pf[q] = AB[gi1 < n ? (size_t)gc * LD + (gi1 - gc) : 0];
+        }
+    }
+    lds_bar();
+    {                                                     // Y = D VT, row block w
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < 16; ++q) acc = MFMA(X[(4 * q + l4) * XLD + 16 * w + l15], VT[(4 * q + l4) * VLD + l15], acc);
+        for (int r = 0; r < 4; ++r) Yb[(16 * w + l4 + 4 * r) * VLD + l15] = acc[r];
+    }
+    lds_bar();
+    {                                                     // M = VT^T Y, split along the rows
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int q = 4 * w; q < 4 * w + 4; ++q) acc = MFMA(VT[(4 * q + l4) * VLD + l15], Yb[(4 * q + l4) * VLD + l15], acc);
+        for (int r = 0; r < 4; ++r) Gp[w * 16 * VLD + (l4 + 4 * r) * VLD + l15] = acc[r];
+    }
+    lds_bar();
+    {
+        const int i = tid >> 4, j = tid & 15, o = i * VLD + j;
+        G[o] = (Gp[o] + Gp[16 * VLD + o]) + (Gp[32 * VLD + o] + Gp[48 * VLD + o]);
+    }
+    lds_bar();
+    {                                                     // Z = Y - 1/2 V M, row block w
+        d4_t acc;
+        for (int r = 0; r < 4; ++r) acc[r] = Yb[(16 * w + l4 + 4 * r) * VLD + l15];
+        for (int q = 0; q < 4; ++q) acc = MFMA(-0.5 * V[(16 * w + l15) * VLD + 4 * q + l4], G[(4 * q + l4) * VLD + l15], acc);
+        for (int r = 0; r < 4; ++r) Z[(16 * w + l4 + 4 * r) * VLD + l15] = acc[r];
+    }
+    lds_bar();
+    for (int bi = w; bi < 10; bi += 4) {                  // D -= V Z^T + Z V^T, the ten 16 x 16 blocks of the lower triangle
+        const int mb = bi < 1 ? 0 : (bi < 3 ? 1 : (bi < 6 ? 2 : 3));
+        const int nb = bi - (mb * (mb + 1)) / 2;
+        d4_t acc;
+        for (int r = 0; r < 4; ++r) acc[r] = X[(16 * nb + l15) * XLD + 16 * mb + l4 + 4 * r];
+        for (int q = 0; q < 4; ++q) {
+            acc = MFMA(-V[(16 * mb + l15) * VLD + 4 * q + l4], Z[(16 * nb + l15) * VLD + 4 * q + l4], acc);
+            acc = MFMA(-Z[(16 * mb + l15) * VLD + 4 * q + l4], V[(16 * nb + l15) * VLD + 4 * q + l4], acc);
+        }
+        for (int r = 0; r < 4; ++r) X[(16 * nb + l15) * XLD + 16 * mb + l4 + 4 * r] = acc[r];
+    }
+    lds_bar();
+    for (int c = w; c < 64; c += 4)
+        if (lane >= c && gi < n) AB[(size_t)(r0 + c) * LD + (lane - c)] = X[c * XLD + lane];
+
+    // ---- next bulge tile
+    if (!more) return;
+    lds_bar();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) X[(w + 4 * q) * XLD + lane] = gi1 < n ? pf[q] : 0.0;
+    lds_bar();
+    {                                                     // W1 = X' VT, row block w
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < 16; ++q) acc = MFMA(X[(4 * q + l4) * XLD + 16 * w + l15], VT[(4 * q + l4) * VLD + l15], acc);
+        for (int r = 0; r < 4; ++r) Yb[(16 * w + l4 + 4 * r) * VLD + l15] = acc[r];
+    }
+    lds_bar();
+    for (int nb = 0; nb < 4; ++nb) {                      // X' -= W1 V^T
+        d4_t acc;
+        for (int r = 0; r < 4; ++r) acc[r] = X[(16 * nb + l15) * XLD + 16 * w + l4 + 4 * r];
+        for (int q = 0; q < 4; ++q) acc = MFMA(-Yb[(16 * w + l15) * VLD + 4 * q + l4], V[(16 * nb + l15) * VLD + 4 * q + l4], acc);
+        for (int r = 0; r < 4; ++r) X[(16 * nb + l15) * XLD + 16 * w + l4 + 4 * r] = acc[r];
+    }
+    lds_bar();
+    for (int c = w; c < 64; c += 4) {
+        const int gc = r0 + c;
+        if (gi1 < n) AB[(size_t)gc * LD + (gi1 - gc)] = X[c * XLD + lane];
+    }
+}
+#undef MFMA
+
+// ---------------------------------------------------------------------------------------------------------------------
 // step 2: band 16 -> tridiagonal.  One workgroup (8 waves) per channel.  Wave w of pass p runs sweep s = 8 p + w; at step t it
 // works on item k = t - 3 w of its sweep.  A 16 x 16 tile lives in a wave as 4 doubles per lane: lane = (row r = lane & 15,
 // column group g = lane >> 4, columns 4 g .. 4 g + 3).
@@ -263,15 +499,109 @@ __device__ __forceinline__ double rsum16(double x)
 }
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Householder parameters from alpha and the squared norm of the rest (> 0): beta, tau = 1 + |alpha| / nrm and
+// 1 / (alpha - beta) = sign(alpha) / (|alpha| + nrm), from v_rsq_f64 / v_rcp_f64 refined by Newton steps (no division, no
+// sqrt expansion: the chase is bound by instruction issue)
+__device__ __forceinline__ void house_params(double alpha, double nrm2, double &beta, double &tq, double &scale)
+{
+    const double nn = alpha * alpha + nrm2;
+    double y = __builtin_amdgcn_rsq(nn);
+    for (int it = 0; it < 3; ++it) y = y * (1.5 - 0.5 * nn * y * y);
+    const double nrm = nn * y, aa = fabs(alpha);
+    beta = -copysign(nrm, alpha);
+    tq = 1.0 + aa * y;
+    const double dd = aa + nrm;
+    double rc = __builtin_amdgcn_rcp(dd);
+    for (int it = 0; it < 3; ++it) rc = rc * (2.0 - dd * rc);
+    scale = copysign(rc, alpha);
+}
+
+// One chase item of a wave: reflector from x = A(r0.., c0), bulge tile B <- H B (k > 0), D <- H D H, next tile B' <- B' H.
+// Layouts: B and D lane = (row r, columns 4g..4g+3); B' transposed, lane = (column r, rows 4g..4g+3): every reduction stays
+// inside a DPP row.
+template <bool FAST>
+__device__ __forceinline__ void chase_item(double *Lw, double *pS, int r0, int c0, int k, int r, int g, int cA, int cT,
+                                           const int (&offD)[4])
+{
+#define LWI(i, c) (((((c)) & (WCOLS - 1)) << 5) + ((i) - (c)))
+    const int r1 = r0 + B2;
+    int ix, ixc[4], ib[4], id[4], it[4];
+    if (FAST) {
+        const int UB = ((c0 & (WCOLS - 1)) << 5) + (r0 - c0), UD = (r0 & (WCOLS - 1)) << 5;
+        ix = UB + r;
+        for (int j = 0; j < 4; ++j) {
+            ixc[j] = UB + 4 * g + j;
+            ib[j] = UB + cA + 31 * j;
+            id[j] = UD + offD[j];
+            it[j] = UD + cT + j;
+        }
+    } else {
+        ix = LWI(r0 + r, c0);
+        for (int j = 0; j < 4; ++j) {
+            const int cc = 4 * g + j;
+            ixc[j] = LWI(r0 + cc, c0);
+            ib[j] = LWI(r0 + r, c0 + cc);
+            id[j] = r >= cc ? LWI(r0 + r, r0 + cc) : LWI(r0 + cc, r0 + r);
+            it[j] = LWI(r1 + cc, r0 + r);
+        }
+    }
+#undef LWI
+    const double x = Lw[ix];
+    double xc[4], b[4], dv[4], bt[4];
+    for (int j = 0; j < 4; ++j) {
+        xc[j] = Lw[ixc[j]];
+        b[j] = k > 0 ? Lw[ib[j]] : 0.0;
+        dv[j] = Lw[id[j]];
+        bt[j] = Lw[it[j]];
+    }
+    const double nrm2 = rsum16(r > 0 ? x * x : 0.0);
+    const double alpha = rdlane(x, 0);
+    double tq = 0.0, scale = 0.0, beta = alpha;
+    if (nrm2 != 0.0) house_params(alpha, nrm2, beta, tq, scale);
+    const double v = r == 0 ? 1.0 : x * scale;
+    double vc[4];
+    for (int j = 0; j < 4; ++j) vc[j] = (4 * g + j) == 0 ? 1.0 : xc[j] * scale;
+    if (g == 0) Lw[ix] = r == 0 ? beta : 0.0;
+    if (k > 0) {                                          // rest of the bulge tile: B <- H B
+        for (int j = 0; j < 4; ++j) {
+            const double dot = rsum16(v * b[j]);
+            if (4 * g + j > 0) Lw[ib[j]] = b[j] - tq * dot * v;
+        }
+    }
+    for (int j = 0; j < 4; ++j) {                          // next bulge tile: B' <- B' H
+        const double q = tq * rsum16(bt[j] * v);
+        Lw[it[j]] = bt[j] - q * v;
+    }
+    // diagonal tile, two-sided: p = tau D v by columns (D is symmetric), by rows through pS
+    double pc[4], part = 0.0;
+    for (int j = 0; j < 4; ++j) {
+        pc[j] = tq * rsum16(v * dv[j]);
+        part += vc[j] * pc[j];
+    }
+    if (r < 4) pS[4 * g + r] = r == 0 ? pc[0] : (r == 1 ? pc[1] : (r == 2 ? pc[2] : pc[3]));
+    const double vtp = (rdlane(part, 0) + rdlane(part, 16)) + (rdlane(part, 32) + rdlane(part, 48));
+    const double kk = 0.5 * tq * vtp;
+    const double w = pS[r] - kk * v;
+    for (int j = 0; j < 4; ++j) {
+        const double wc = pc[j] - kk * vc[j];
+        if (r >= 4 * g + j) Lw[id[j]] = dv[j] - v * wc - w * vc[j];
+    }
+}
+
 __global__ __launch_bounds__(576) void sb16st_kernel(int n, int npad, double *__restrict__ ABall, double *__restrict__ dall,
                                                      double *__restrict__ eall, long long *diag)
 {
     extern __shared__ double lds[];
     double *Lw = lds;
     long long dacc[5] = {0, 0, 0, 0, 0}, dt0 = 0;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     double *pS = lds + WCOLS * WROWS + (wv & 7) * 16;
+    // lane constants of the fast path, in doubles relative to element (r0, c0) resp. (r0, r0) of the window:
+    // element (r0 + a, c + b) lies 31 b + a further
+    const int cA = 124 * g + r, cT = 31 * r + 4 * g + 16;
+    int offD[4];
+    for (int j = 0; j < 4; ++j) offD[j] = r >= 4 * g + j ? cA + 31 * j : 31 * r + 4 * g + j;
     double *AB = ABall + blockIdx.x * ab_stride(npad);
 #define LW(i, c) Lw[((((c)) & (WCOLS - 1)) << 5) + ((i) - (c))]
 
@@ -324,59 +654,10 @@ __global__ __launch_bounds__(576) void sb16st_kernel(int n, int npad, double *__
             if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime();
             if (wv < NW2 && k >= 0 && s < n - 2 && r0 < n) {
                 const int c0 = k == 0 ? s : r0 - B2;
-                const int r1 = r0 + B2;
-                // everything the item reads, requested at once.  Layouts: B and D tiles lane = (row r, columns 4g..4g+3);
-                // the next bulge tile transposed, lane = (column r, rows 4g..4g+3): every reduction stays inside a DPP row
-                const double x = LW(r0 + r, c0);
-                double xc[4], b[4], dv[4], bt[4];
-                for (int j = 0; j < 4; ++j) {
-                    const int cc = 4 * g + j;
-                    xc[j] = LW(r0 + cc, c0);
-                    b[j] = k > 0 ? LW(r0 + r, c0 + cc) : 0.0;
-                    dv[j] = r >= cc ? LW(r0 + r, r0 + cc) : LW(r0 + cc, r0 + r);
-                    bt[j] = LW(r1 + cc, r0 + r);
-                }
-                if (diag) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[0] += t_ - dt0; dt0 = t_; }
-                const double nrm2 = rsum16(r > 0 ? x * x : 0.0);
-                const double alpha = rdlane(x, 0);
-                double tq = 0.0, scale = 0.0, beta = alpha;
-                if (nrm2 != 0.0) {
-                    beta = -copysign(sqrt(alpha * alpha + nrm2), alpha);
-                    tq = (beta - alpha) / beta;
-                    scale = 1.0 / (alpha - beta);
-                }
-                const double v = r == 0 ? 1.0 : x * scale;
-                double vc[4];
-                for (int j = 0; j < 4; ++j) vc[j] = (4 * g + j) == 0 ? 1.0 : xc[j] * scale;
-                if (g == 0) LW(r0 + r, c0) = r == 0 ? beta : 0.0;
-                if (diag) { asm volatile("" :: "v"(v)); const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[1] += t_ - dt0; dt0 = t_; }
-                // rest of the bulge tile: B <- H B
-                if (k > 0) {
-                    for (int j = 0; j < 4; ++j) {
-                        const double dot = rsum16(v * b[j]);
-                        if (4 * g + j > 0) LW(r0 + r, c0 + 4 * g + j) = b[j] - tq * dot * v;
-                    }
-                }
-                // next bulge tile: B' <- B' H (transposed layout: the row sums are sums over a DPP row)
-                for (int j = 0; j < 4; ++j) {
-                    const double q = tq * rsum16(bt[j] * v);
-                    LW(r1 + 4 * g + j, r0 + r) = bt[j] - q * v;
-                }
-                // diagonal tile, two-sided: p = tau D v by columns (D is symmetric), by rows through pS
-                double pc[4], part = 0.0;
-                for (int j = 0; j < 4; ++j) {
-                    pc[j] = tq * rsum16(v * dv[j]);
-                    part += vc[j] * pc[j];
-                }
-                if (r < 4) pS[4 * g + r] = r == 0 ? pc[0] : (r == 1 ? pc[1] : (r == 2 ? pc[2] : pc[3]));
-                const double vtp = (rdlane(part, 0) + rdlane(part, 16)) + (rdlane(part, 32) + rdlane(part, 48));
-                const double kk = 0.5 * tq * vtp;
-                const double w = pS[r] - kk * v;
-                for (int j = 0; j < 4; ++j) {
-                    const int cc = 4 * g + j;
-                    const double wc = pc[j] - kk * vc[j];
-                    if (r >= cc) LW(r0 + r, r0 + cc) = dv[j] - v * wc - w * vc[j];
-                }
+                // a tile whose 16 columns do not wrap around the ring (9 in 10) is addressed with lane constants and immediates
+                const bool fast = (c0 & (WCOLS - 1)) <= WCOLS - 16 && (r0 & (WCOLS - 1)) <= WCOLS - 16;
+                if (fast) chase_item<true>(Lw, pS, r0, c0, k, r, g, cA, cT, offD);
+                else chase_item<false>(Lw, pS, r0, c0, k, r, g, cA, cT, offD);
                 if (diag) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[2] += t_ - dt0; dt0 = t_; }
             }
             lds_only_barrier();
@@ -408,8 +689,11 @@ int launch_sb2sb(int n, int npad, int batch, double *d_AB, hipStream_t st)
     if (!attr) {
         BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sb2sb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     SB2SB_LDS));
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sb2sb_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    SB2SB2_LDS));
         attr = true;
     }
+    const bool mf = opts().sb2sb_mfma != 0;
     const int S = (n - NB1 + NB1 - 1) / NB1;                       // sweeps: j0 + 16 < n
     auto K = [n](int s) { const int m = n - (NB1 * s + NB1); return m > 0 ? (m + B1 - 1) / B1 : 0; };
     int tmax = -1;
@@ -421,7 +705,8 @@ int launch_sb2sb(int n, int npad, int batch, double *d_AB, hipStream_t st)
         if (t - LAG * s_hi >= K(s_hi)) continue;
         int s_lo = s_hi;
         while (s_lo > 0 && t - LAG * (s_lo - 1) < K(s_lo - 1)) --s_lo;
-        hipLaunchKernelGGL(sb2sb_kernel, dim3(s_hi - s_lo + 1, batch), dim3(256), SB2SB_LDS, st, n, npad, d_AB, t, s_lo);
+        if (mf) hipLaunchKernelGGL(sb2sb_mfma_kernel, dim3(s_hi - s_lo + 1, batch), dim3(256), SB2SB2_LDS, st, n, npad, d_AB, t, s_lo);
+        else hipLaunchKernelGGL(sb2sb_kernel, dim3(s_hi - s_lo + 1, batch), dim3(256), SB2SB_LDS, st, n, npad, d_AB, t, s_lo);
     }
     BSP_HIP(hipGetLastError());
     return BSP_OK;
