@@ -238,13 +238,47 @@ def main():
         # touch); bytes_pass_model: what the two-sweeps-per-pass scheme moves by construction (an item's tiles read by
         # the first sweep of a pair, written by the second: 6 n^2 b B per channel).
         sb_min = (2.0 * b * n * 8 + 16.0 * n) * nl
-        sb_model = 6.0 * n * n * b * nl
-        kern.append({"kernel": "sb2st_kernel_v7<0>", "bound": "hbm", "launch_ms": sb_ms, "launch_ms_source": "HIP events, this run",
-                     "bytes_min": sb_min, "bytes_pass_model": sb_model,
-                     "achieved": sb_model / (sb_ms * 1e-3) / 1e9 if sb_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": sb_model / (sb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sb_ms > 0 else None,
-                     "frac_of_min_bytes": sb_min / (sb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sb_ms > 0 else None,
-                     "traffic": pmc_bytes("sb2st_kernel_v7"), "traffic_source": pmc_file})
+        ver = capi.get_option("sb2st_version")
+        two_step = ver == 9 or (ver == 0 and n >= 512)
+
+        def from_stats(sub):
+            hit = [(k, v) for k, v in kstats.items() if sub in k]
+            if not hit:
+                return None
+            calls = sum(v[1] for _, v in hit)
+            return {"launches_per_step": calls / 5.0, "avg_launch_ms": sum(v[0] * v[1] for _, v in hit) / calls,
+                    "kernel_ms_per_step": sum(v[0] * v[1] for _, v in hit) / 5.0, "source": stats_file,
+                    "traffic_bytes_per_launch": pmc_bytes(sub), "traffic_source": pmc_file}
+
+        if two_step:
+            # Two steps (csrc/sbr2.hip).  Step 1, sb2sb_mfma_kernel: one launch per wavefront of independent chase items (sweep of
+            # 16 columns s, step k, t = k + 3 s); an item reads and writes a 64 x 64 bulge tile, the lower triangle of a 64 x 64
+            # diagonal tile and the next 64 x 64 tile.  Step 2, sb16st_kernel: ONE launch; every pass of 8 sweeps streams the
+            # remaining band (32 rows of 8 B per column) through an LDS window once: read + write.
+            items = sum(max(0, -(-(n - 16 * (s_ + 1)) // 64)) for s_ in range((n - 1) // 16))
+            b1 = items * (2 * 64 * 64 * 8 + 2 * 2080 * 8 + 2 * 64 * 64 * 8) * nl
+            b2 = sum(2 * 32 * 8 * (n - s0_) for s0_ in range(0, n - 2, 8)) * nl
+            kern.append({"kernel": "sb2sb_mfma_kernel (band 64 -> 16, one launch per wavefront) + sb16st_kernel (band 16 -> 1, one launch)",
+                         "bound": "hbm", "launch_ms": sb_ms, "launch_ms_source": "HIP events around the stage, this run",
+                         "bytes_min": sb_min, "bytes_model": b1 + b2, "bytes_model_sb2sb": b1, "bytes_model_sb16st": b2,
+                         "chase_items_sb2sb_per_channel": items,
+                         "achieved": (b1 + b2) / (sb_ms * 1e-3) / 1e9 if sb_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (b1 + b2) / (sb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sb_ms > 0 else None,
+                         "split_from_profile": {"sb2sb_mfma_kernel": from_stats("sb2sb_mfma_kernel"),
+                                                "sb16st_kernel": from_stats("sb16st_kernel")},
+                         "traffic": (sum(v["traffic_bytes_per_launch"] * v["launches"] for k_, v in pmc["kernels"].items()
+                                         if "sb2sb_mfma_kernel" in k_ or "sb16st_kernel" in k_) or None) if pmc else None,
+                         "traffic_source": pmc_file,
+                         "note": "step 2 is bound by the serial chase (one 16 x 16 item per wave and step, ~1.8 us per step), "
+                                 "not by memory; step 1 by item latency at two workgroups per CU"})
+        else:
+            sb_model = 6.0 * n * n * b * nl
+            kern.append({"kernel": "sb2st_kernel_v7<0>", "bound": "hbm", "launch_ms": sb_ms, "launch_ms_source": "HIP events, this run",
+                         "bytes_min": sb_min, "bytes_pass_model": sb_model,
+                         "achieved": sb_model / (sb_ms * 1e-3) / 1e9 if sb_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": sb_model / (sb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sb_ms > 0 else None,
+                         "frac_of_min_bytes": sb_min / (sb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sb_ms > 0 else None,
+                         "traffic": pmc_bytes("sb2st_kernel_v7"), "traffic_source": pmc_file})
         # rank-128 update executes 0.55 of 2 n^3 / 3 ... per channel: sum over panels of the valid tiles; symm 2 n^3 / 3
         for kname, flop, label in (("gemm2_kernel<128, 128", 0.55 * 4.0 / 3.0 * n ** 3 * nl, "rank-128 update (syr2k)"),
                                    ("gemm2_kernel<64, 128", 2.0 / 3.0 * n ** 3 * nl, "symm Y = A22 W")):
@@ -273,9 +307,9 @@ def main():
                 "frac": ach / (FP64_PEAK_TFLOPS * world),
                 "scope": "whole path: F(n) = 4/3 n^3 + 4 n^2 k flop per l-channel (SURVEY 8d) x eigensolves/s, against the fp64 "
                          "matrix/vector peak of %d GPU(s)" % world,
-                "traffic": pmc_bytes("sb2st_kernel_v7"),
-                "traffic_note": "HBM bytes per launch of the longest single kernel (sb2st), from the committed profile %s -- "
-                                "not measured in this run" % pmc_file,
+                "traffic": (sum(v["traffic_bytes_per_launch"] * v["launches"] for v in pmc["kernels"].values()) if pmc else None),
+                "traffic_note": "HBM bytes of ONE STEP (all kernels: sum of launches x bytes per launch), from the committed profile "
+                                "%s -- not measured in this run" % pmc_file,
                 "kernels": kern}
         out = {
             "metric": "l-channel eigensolves/sec at N_bsp=%d fp64" % n, "value": value, "unit": "eigensolves/s",

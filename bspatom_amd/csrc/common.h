@@ -36,7 +36,7 @@ namespace bsp {
 // Read ONCE per process from the environment (BSP_* variables) at the first use; the tests flip
 // them in-process through bspatom_set_option (include/bspatom.h) to drive the fallback paths.
 struct Options {
-    int sb2st_version = 8;       // BSP_SB2ST_VERSION: 8 = two-sweep workgroups in rings, 7 = one per channel, 3 = one sweep per workgroup
+    int sb2st_version = 0;       // 0: by size (9 = two steps, sbr2.hip, for n >= 512; else 8); 9 / 8 / 7 / 3 force a generation
     int sb2st_ring = 0;          // BSP_SB2ST_RING: ring size (0 = by channel count)
     int sb2st_margin = 3, sb2st_hyst = 2;
     int sb2st_lead = 0;          // BSP_SB2ST_LEAD: 0 = by ring size (pairs: 8, larger rings: 16; re-scan of round 2)
@@ -131,7 +131,7 @@ int launch_extract_band(int npad, int nb, int batch, const double *d_A, double *
 size_t sb2st_ctl_bytes(int batch);
 // two-step route (sbr2.hip): band 64 -> 16 by block bulge chasing, then 16 -> tridiagonal in an LDS window
 int launch_sb2sb(int n, int npad, int batch, double *d_AB, hipStream_t st);
-int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st);
+int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st, int *d_status = nullptr);
 int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, double *d_e,
                  hipStream_t st, int *d_status = nullptr, void *ctl = nullptr);
 // tridiag.hip

@@ -1299,7 +1299,8 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
                  void *ctl)
 {
     if (b != SB) return BSP_ERR_ARG;
-    const int ver = opts().sb2st_version;
+    int ver = opts().sb2st_version;
+    if (ver == 0) ver = n >= 512 ? 9 : 8;                  // two steps wherever there is enough to chase
     // 8 (default): two-sweep workgroups in rings of P per channel; 7: one two-sweep workgroup per channel; 3: one
     // one-sweep workgroup per channel (an independent implementation of the same chase, kept as the cross-check of
     // tests/test_gpu_solve.py::test_sb2st_fallback_paths); v1, v2, v4, v6 are in the history only
@@ -1307,7 +1308,7 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
     if (ver == 9) {
         int rc;
         if ((rc = launch_sb2sb(n, npad, batch, d_AB, st))) return rc;
-        return launch_sb16st(n, npad, batch, d_AB, d_d, d_e, st);
+        return launch_sb16st(n, npad, batch, d_AB, d_d, d_e, st, d_status);
     }
     if (ver != 3 && ver != 7 && ver != 8) return BSP_ERR_ARG;
     if (ver == 7 || ver == 8) {

@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void sb2sb_mfma_kernel(int n, int npad, double
 // works on item k = t - 3 w of its sweep.  A 16 x 16 tile lives in a wave as 4 doubles per lane: lane = (row r = lane & 15,
 // column group g = lane >> 4, columns 4 g .. 4 g + 3).
 constexpr int B2 = 16, NW2 = 8, WCOLS = 512, WROWS = 32;
-constexpr int SB16_LDS = (WCOLS * WROWS + NW2 * 16) * 8;
+constexpr int SB16_LDS = (WCOLS * WROWS + NW2 * 16 + 2) * 8;
 
 template <int CTRL>
 __device__ __forceinline__ double dppd(double x)
@@ -499,21 +499,14 @@ __device__ __forceinline__ double rsum16(double x)
 }
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Householder parameters from alpha and the squared norm of the rest (> 0): beta, tau = 1 + |alpha| / nrm and
-// 1 / (alpha - beta) = sign(alpha) / (|alpha| + nrm), from v_rsq_f64 / v_rcp_f64 refined by Newton steps (no division, no
-// sqrt expansion: the chase is bound by instruction issue)
+// Householder parameters from alpha and the squared norm of the rest (> 0), with IEEE sqrt and divisions.  (v_rsq_f64 /
+// v_rcp_f64 + three Newton steps were 2 ms faster per 128-channel step and cost the eigenvalues next to zero their accuracy: C5
+// went from 2 to 27 exceptions to 1e-10 relative; the graded pencils notice a few ulp in tau.)
 __device__ __forceinline__ void house_params(double alpha, double nrm2, double &beta, double &tq, double &scale)
 {
-    const double nn = alpha * alpha + nrm2;
-    double y = __builtin_amdgcn_rsq(nn);
-    for (int it = 0; it < 3; ++it) y = y * (1.5 - 0.5 * nn * y * y);
-    const double nrm = nn * y, aa = fabs(alpha);
-    beta = -copysign(nrm, alpha);
-    tq = 1.0 + aa * y;
-    const double dd = aa + nrm;
-    double rc = __builtin_amdgcn_rcp(dd);
-    for (int it = 0; it < 3; ++it) rc = rc * (2.0 - dd * rc);
-    scale = copysign(rc, alpha);
+    beta = -copysign(sqrt(alpha * alpha + nrm2), alpha);
+    tq = (beta - alpha) / beta;
+    scale = 1.0 / (alpha - beta);
 }
 
 // One chase item of a wave: reflector from x = A(r0.., c0), bulge tile B <- H B (k > 0), D <- H D H, next tile B' <- B' H.
@@ -588,8 +581,36 @@ __device__ __forceinline__ void chase_item(double *Lw, double *pS, int r0, int c
     }
 }
 
-__global__ __launch_bounds__(576) void sb16st_kernel(int n, int npad, double *__restrict__ ABall, double *__restrict__ dall,
-                                                     double *__restrict__ eall, long long *diag)
+// Control block of one channel when P workgroups share its passes (member w runs the passes w, w + P, ...; pass p + 1 follows
+// pass p through global memory).  Same rules as the rings of sb2st.hip (documented there): the members must share an XCD
+// (one L2) -- blocks b, b + 8, ... are observed to, every member reports HW_REG_XCC_ID and the ring forms only if they agree,
+// otherwise (or if a member does not show up in time) member 0 runs the channel alone; data is handed over with plain
+// stores + s_waitcnt vmcnt(0) + a relaxed agent-scope store of the progress word, and taken with a relaxed poll of that
+// word + buffer_inv sc1 (drops the CU's L1 lines) before the plain loads.  Every spin is bounded.
+struct Sb16Ctl {
+    unsigned long long hs;                 // handshake: byte w = 0x10 | XCC id of member w; bit 62 COMMIT, bit 63 ABORT
+    int err, pad;
+    unsigned long long prog[8];            // member w: (pass << 32) | columns of that pass already stored (n when it is complete)
+};
+constexpr unsigned long long S16_COMMIT = 1ull << 62, S16_ABORT = 1ull << 63;
+
+__device__ __forceinline__ void s16_wait(const unsigned long long *pollp, unsigned long long want, Sb16Ctl *C, int *status)
+{
+    int spin = 0;
+    while (__hip_atomic_load(pollp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        if (++spin > 20000000) {                          // never seen; ends the wait instead of the machine
+            atomicExch(&C->err, 1);
+            if (status) atomicExch(status, BSP_ERR_HIP);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    asm volatile("buffer_inv sc1" ::: "memory");
+}
+
+__global__ __launch_bounds__(576) void sb16st_kernel(int n, int npad, int batch, double *__restrict__ ABall,
+                                                     double *__restrict__ dall, double *__restrict__ eall, long long *diag,
+                                                     Sb16Ctl *ctl, int P, int *status, int force_abort)
 {
     extern __shared__ double lds[];
     double *Lw = lds;
@@ -602,12 +623,63 @@ __global__ __launch_bounds__(576) void sb16st_kernel(int n, int npad, double *__
     const int cA = 124 * g + r, cT = 31 * r + 4 * g + 16;
     int offD[4];
     for (int j = 0; j < 4; ++j) offD[j] = r >= 4 * g + j ? cA + 31 * j : 31 * r + 4 * g + j;
-    double *AB = ABall + blockIdx.x * ab_stride(npad);
+    // ---- which channel; alone (ctl == nullptr) or member w of a ring of P workgroups
+    int chn = blockIdx.x, w = 0, stride = 1;
+    const unsigned long long *pollp = nullptr;
+    unsigned long long *pubp = nullptr;
+    Sb16Ctl *C = nullptr;
+    if (ctl) {
+        const int blk = blockIdx.x, grp = blk / (8 * P), rr = blk % (8 * P);
+        chn = grp * 8 + (rr & 7); w = rr >> 3;
+        if (chn >= batch) return;
+        C = ctl + chn;
+        int *modep = reinterpret_cast<int *>(lds + WCOLS * WROWS + NW2 * 16);
+        if (tid == 0) {
+            const unsigned long long xcc = (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu);   // HW_REG_XCC_ID
+            const unsigned long long mine = (0x10ull | xcc) << (8 * w);
+            unsigned long long full = 0;
+            for (int q = 0; q < P; ++q) full |= 0x10ull << (8 * q);
+            unsigned long long v = atomicOr(&C->hs, mine) | mine;
+            for (int spin = 0; !(v & (S16_COMMIT | S16_ABORT)); ++spin) {
+                if (force_abort == 1) atomicCAS(&C->hs, v, v | S16_ABORT);
+                else if ((v & full) == full) atomicCAS(&C->hs, v, v | S16_COMMIT);
+                else if (spin > 400000) atomicCAS(&C->hs, v, v | S16_ABORT);
+                else __builtin_amdgcn_s_sleep(4);
+                v = __hip_atomic_load(&C->hs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            int mode;                                     // 0 = exit, 1 = ring, 2 = alone
+            if (v & S16_ABORT) mode = (w == 0) ? 2 : 0;
+            else {
+                bool same = true;
+                for (int q = 1; q < P; ++q) same = same && (((v >> (8 * q)) & 0xfu) == (v & 0xfu));
+                if (force_abort == 2) same = false;
+                mode = same ? 1 : ((w == 0) ? 2 : 0);
+            }
+            *modep = mode;
+        }
+        __syncthreads();
+        const int mode = __builtin_amdgcn_readfirstlane(*modep);
+        __syncthreads();
+        if (mode == 0) return;
+        if (mode == 1 && P > 1) { stride = P; pollp = &C->prog[(w + P - 1) % P]; pubp = &C->prog[w]; }
+        else w = 0;
+    }
+    double *AB = ABall + (size_t)chn * ab_stride(npad);
 #define LW(i, c) Lw[((((c)) & (WCOLS - 1)) << 5) + ((i) - (c))]
 
     double *dump = AB + (size_t)npad * LD + 64;              // padding behind the band (ab_stride): target of masked stores
-    for (int s0 = 0; s0 < n - 2; s0 += NW2) {
+    const int npass = (n - 2 + NW2 - 1) / NW2;
+    for (int ps = w; ps < npass; ps += stride) {
+        const int s0 = ps * NW2;
         int RP = s0, LP = s0 + 64;
+        if (pollp && ps > 0) {                            // the first 128 columns of this pass, as the pass before left them
+            if (tid == 0) {
+                const int need = s0 + 128 < n ? s0 + 128 : n;
+                s16_wait(pollp, ((unsigned long long)(ps - 1) << 32) + (unsigned)need, C, status);
+            }
+            __syncthreads();
+            asm volatile("buffer_inv sc1" ::: "memory");
+        }
         for (int idx = tid; idx < 64 * WROWS; idx += 576) {
             const int c = s0 + (idx >> 5), d = idx & 31;
             Lw[((c & (WCOLS - 1)) << 5) + d] = c + d < n ? AB[(size_t)c * LD + d] : 0.0;
@@ -641,6 +713,16 @@ __global__ __launch_bounds__(576) void sb16st_kernel(int n, int npad, double *__
                         const int c = LP + 2 * i + mh;
                         Lw[((c & (WCOLS - 1)) << 5) + md] = c + md < n ? qb[i] : 0.0;
                     }
+                    if (pubp) {                           // everything stored before this step has reached the L2
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0)
+                            __hip_atomic_store(pubp, ((unsigned long long)ps << 32) + (unsigned)RP, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (pollp && ps > 0 && LP + 64 < n) {
+                        const int need = LP + 128 < n ? LP + 128 : n;
+                        s16_wait(pollp, ((unsigned long long)(ps - 1) << 32) + (unsigned)need, C, status);
+                    }
                     for (int i = 0; i < 32; ++i) {
                         const int c = LP + 64 + 2 * i + mh;
                         qb[i] = AB[c + md < n ? (size_t)c * LD + md : 0];
@@ -670,11 +752,16 @@ __global__ __launch_bounds__(576) void sb16st_kernel(int n, int npad, double *__
             AB[(size_t)c * LD + d] = Lw[((c & (WCOLS - 1)) << 5) + d];
         }
         __syncthreads();
+        if (pubp && tid == 0)
+            __hip_atomic_store(pubp, ((unsigned long long)ps << 32) + (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #undef LW
     if (diag && blockIdx.x == 0 && lane == 0)
         for (int q = 0; q < 5; ++q) diag[wv * 5 + q] = dacc[q];
-    double *dd = dall + blockIdx.x * (size_t)npad, *ee = eall + blockIdx.x * (size_t)npad;
+    if (stride > 1 && (npass - 1) % stride != w && npass > 0) return;   // the member of the last pass has seen every pass end
+    __syncthreads();
+    asm volatile("buffer_inv sc1" ::: "memory");
+    double *dd = dall + (size_t)chn * npad, *ee = eall + (size_t)chn * npad;
     for (int j = tid; j < n; j += 576) {
         dd[j] = AB[(size_t)j * LD];
         ee[j] = j < n - 1 ? AB[(size_t)j * LD + 1] : 0.0;
@@ -712,7 +799,7 @@ int launch_sb2sb(int n, int npad, int batch, double *d_AB, hipStream_t st)
     return BSP_OK;
 }
 
-int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st)
+int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st, int *d_status)
 {
     static bool attr = false;
     if (!attr) {
@@ -720,20 +807,39 @@ int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double 
                                     SB16_LDS));
         attr = true;
     }
+    // workgroups per channel: as many as the chip has CUs for (each needs a whole CU's LDS), at most 8
+    int P = opts().sb2st_ring > 0 ? opts().sb2st_ring : (batch > 128 ? 1 : (batch > 64 ? 2 : (batch > 32 ? 4 : 8)));
+    if (P > 8) P = 8;
+    while (P > 1 && (n - 2) / NW2 < 2 * P) P /= 2;         // fewer passes than members: nothing to share
+    static Sb16Ctl *s_ctl = nullptr;
+    static int cap = 0;
+    Sb16Ctl *d_ctl = nullptr;
+    if (P > 1) {
+        if (cap < batch) {
+            if (s_ctl) hipFree(s_ctl);
+            BSP_HIP(hipMalloc(reinterpret_cast<void **>(&s_ctl), (size_t)batch * sizeof(Sb16Ctl)));
+            cap = batch;
+        }
+        d_ctl = s_ctl;
+        BSP_HIP(hipMemsetAsync(d_ctl, 0, (size_t)batch * sizeof(Sb16Ctl), st));
+    }
+    const int nblk = P > 1 ? ((batch + 7) / 8) * 8 * P : batch;
+    const int fab = opts().sb2st_force_abort;
     if (opts().sb2st_diag) {                                // cycles per phase of the chasing waves (workgroup 0)
         long long *dbuf = nullptr, h[45];
         BSP_HIP(hipMalloc(reinterpret_cast<void **>(&dbuf), sizeof(h)));
-        hipLaunchKernelGGL(sb16st_kernel, dim3(batch), dim3(576), SB16_LDS, st, n, npad, d_AB, d_d, d_e, dbuf);
+        hipLaunchKernelGGL(sb16st_kernel, dim3(nblk), dim3(576), SB16_LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf, d_ctl, P,
+                           d_status, fab);
         BSP_HIP(hipStreamSynchronize(st));
         BSP_HIP(hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost));
         hipFree(dbuf);
         for (int w = 0; w < 9; ++w)
-            fprintf(stderr, "sb16st wave %d: steps %lld; cycles per step (100 MHz ticks x 24): tile loads %.0f, reflector %.0f, products + stores %.0f, rest + barrier %.0f\n",
-                    w, h[w * 5 + 4], 24.0 * h[w * 5] / h[w * 5 + 4], 24.0 * h[w * 5 + 1] / h[w * 5 + 4], 24.0 * h[w * 5 + 2] / h[w * 5 + 4],
-                    24.0 * h[w * 5 + 3] / h[w * 5 + 4]);
+            fprintf(stderr, "sb16st wave %d: %lld steps; s_memtime ticks per step: chase item %.0f, rest + barrier %.0f\n", w, h[w * 5 + 4],
+                    (double)h[w * 5 + 2] / h[w * 5 + 4], (double)h[w * 5 + 3] / h[w * 5 + 4]);
         return BSP_OK;
     }
-    hipLaunchKernelGGL(sb16st_kernel, dim3(batch), dim3(576), SB16_LDS, st, n, npad, d_AB, d_d, d_e, (long long *)nullptr);
+    hipLaunchKernelGGL(sb16st_kernel, dim3(nblk), dim3(576), SB16_LDS, st, n, npad, batch, d_AB, d_d, d_e, (long long *)nullptr,
+                       d_ctl, P, d_status, fab);
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }

@@ -29,7 +29,7 @@ def test_bench_under_torchrun_one_rank(scaling):
     assert "RCCL" in d["config"]["parallelism"]
     assert d["rydberg_max_rel_err_n<=8"] < 1e-4        # n = 8 reaches the wall of the rb = 200 box (1.5e-5); n <= 4: 1e-10
     r = d["roofline"]
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernels"][0]["kernel"].startswith("sb2st")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernels"][0]["kernel"].startswith("sb2sb")
 
 
 def test_sharded_host_under_torchrun(tmp_path):

@@ -513,11 +513,13 @@ def test_sb2st_fallback_paths():
       version 3."""
     inp = input_from_case("c3_1024_l31")
     prob = capi.Problem(inp)
-    E0, info = prob.solve(0, 12)
+    with _Options(sb2st_version=8):
+        E0, info = prob.solve(0, 12)
     assert np.all(info == 0)
     lam = np.max(np.abs(E0))
     for kw in [dict(sb2st_ring=8), dict(sb2st_ring=4), dict(sb2st_ring=2), dict(sb2st_version=7),
                dict(sb2st_force_abort=1), dict(sb2st_force_abort=2), dict(sb2st_ring=8, sb2st_force_abort=1)]:
+        kw.setdefault("sb2st_version", 8)
         with _Options(**kw):
             E, info = prob.solve(0, 12)
         assert np.all(info == 0), kw
@@ -525,14 +527,30 @@ def test_sb2st_fallback_paths():
     with _Options(sb2st_version=3):
         E, info = prob.solve(0, 12)
     assert np.all(info == 0)
-    note("sb2st version 3 vs default: normwise %.2e" % (np.max(np.abs(E - E0)) / lam))
+    note("sb2st version 3 vs 8: normwise %.2e" % (np.max(np.abs(E - E0)) / lam))
     assert np.max(np.abs(E - E0)) <= 1e-13 * lam
+    # the default at this size is the two-step route (version 9, csrc/sbr2.hip): rings of 8 / 4 / 2 workgroups and one
+    # workgroup per channel in its second step, the ABORT and 'different XCDs' fallbacks of its handshake -- bit for bit among
+    # themselves, to rounding against the one-step route
+    E9, info = prob.solve(0, 12)
+    assert np.all(info == 0)
+    note("sb2st default (two steps) vs 8: normwise %.2e" % (np.max(np.abs(E9 - E0)) / lam))
+    assert np.max(np.abs(E9 - E0)) <= 1e-13 * lam
+    for kw in [dict(sb2st_ring=8), dict(sb2st_ring=4), dict(sb2st_ring=2), dict(sb2st_ring=1), dict(sb2st_force_abort=1),
+               dict(sb2st_force_abort=2), dict(sb2sb_mfma=0)]:
+        with _Options(sb2st_version=9, **kw):
+            E, info = prob.solve(0, 12)
+        assert np.all(info == 0), kw
+        if "sb2sb_mfma" in kw:                 # the first, all-VALU block-chasing kernel: another order of the same sums
+            assert np.max(np.abs(E - E9)) <= 1e-13 * lam
+        else:
+            assert np.array_equal(E, E9), (kw, np.max(np.abs(E - E9)) / lam)
     prob.close()
 
 
 def test_two_step_band_reduction_route():
-    """sb2st_version 9 (csrc/sbr2.hip: band 64 -> 16 by block bulge chasing, 16 -> tridiagonal in an LDS window; experimental, not
-    the default): the whole solve on C2 (n = 2048) against the reference spectrum and the truth, same bar as the default route;
+    """sb2st_version 9 (csrc/sbr2.hip: band 64 -> 16 by block bulge chasing, 16 -> tridiagonal in an LDS window; the default
+    for n >= 512): the whole solve on C2 (n = 2048) against the reference spectrum and the truth, same bar as the default route;
     12 channels at n = 1024 against the default route to rounding, and bit-identical when repeated."""
     prob = capi.Problem(input_from_case("c2_2048"))
     with _Options(sb2st_version=9):
@@ -581,7 +599,7 @@ def test_sizes_beyond_the_build_are_refused_at_create():
 def test_unknown_option_is_rejected():
     with pytest.raises(capi.BspAtomError):
         capi.set_option("no_such_switch", 1)
-    assert capi.get_option("sb2st_version") == 8
+    assert capi.get_option("sb2st_version") == 0
 
 
 def test_state_is_invalidated_by_assemble():
@@ -808,20 +826,23 @@ print("noise iterations", it)
 
 
 def test_sb2st_handoff_under_uneven_load(tmp_path):
-    """The ring members of the bulge chasing hand tiles to each other through the XCD's L2 with relaxed agent-scope progress
-    words (csrc/sb2st.hip, 'THE HAND-OFF BETWEEN RING MEMBERS').  MI355X_MICROARCH.md: test every hand-off under UNEVEN load --
+    """The ring members of the bulge chasing hand tiles (one-step route, csrc/sb2st.hip, 'THE HAND-OFF BETWEEN RING MEMBERS') or
+    retired band columns (second step of the two-step route, csrc/sbr2.hip: Sb16Ctl) to each other through the XCD's L2 with
+    relaxed agent-scope progress words.  MI355X_MICROARCH.md: test every hand-off under UNEVEN load --
     idle chips and uniform load hide stale reads.  While 128 channels at n = 4096 are solved, a second process keeps a varying
     part of the same GPU busy with unrelated kernels (matrix products of changing size, memory fills), so ring members start
     late, share CUs with foreign workgroups and hold at different places than in a quiet run.  The spectra must not differ from
     the quiet run's by a single bit; rings of 2 (default at 128 channels) and of 8 and 4 (on 32 channels)."""
     import subprocess, sys, time
     prob = capi.Problem(input_from_case("c4_4096", l_fin=127))
-    cases = ((128, 0), (32, 8), (32, 4))
+    # (channels, ring, generation): the default two-step route (9: pairs of workgroups share the passes of its second step at 128
+    # channels, rings of 8 / 4 at 32) and the one-step route (8)
+    cases = ((128, 0, 9), (32, 8, 9), (32, 4, 9), (128, 0, 8), (32, 8, 8), (32, 4, 8))
     quiet, tq = {}, {}
-    for nl, ring in cases:
-        with _Options(sb2st_ring=ring):
-            quiet[(nl, ring)], info = prob.solve(0, nl)
-        tq[(nl, ring)] = prob.last_timing()["sb2st"]
+    for nl, ring, ver in cases:
+        with _Options(sb2st_ring=ring, sb2st_version=ver):
+            quiet[(nl, ring, ver)], info = prob.solve(0, nl)
+        tq[(nl, ring, ver)] = prob.last_timing()["sb2st"]
         assert np.all(info == 0)
     script = tmp_path / "noise.py"; script.write_text(_NOISE)
     ready, stop = tmp_path / "ready", tmp_path / "stop"
@@ -834,12 +855,12 @@ def test_sb2st_handoff_under_uneven_load(tmp_path):
             time.sleep(0.2)
         tn = {}
         for rep in range(2):
-            for nl, ring in cases:
-                with _Options(sb2st_ring=ring):
+            for nl, ring, ver in cases:
+                with _Options(sb2st_ring=ring, sb2st_version=ver):
                     E, info = prob.solve(0, nl)
-                tn[(nl, ring)] = prob.last_timing()["sb2st"]
+                tn[(nl, ring, ver)] = prob.last_timing()["sb2st"]
                 assert np.all(info == 0)
-                assert np.array_equal(E, quiet[(nl, ring)]), (nl, ring, rep, float(np.max(np.abs(E - quiet[(nl, ring)]))))
+                assert np.array_equal(E, quiet[(nl, ring, ver)]), (nl, ring, ver, rep, float(np.max(np.abs(E - quiet[(nl, ring, ver)]))))
     finally:
         stop.write_text("stop")
         out = child.communicate(timeout=120)[0]
@@ -847,7 +868,8 @@ def test_sb2st_handoff_under_uneven_load(tmp_path):
     iters = int(out.strip().split()[-1])
     assert iters >= 3, out                                   # the foreign kernels really ran beside the solves
     note("sb2st hand-off under uneven load (%d foreign iterations): bit-identical; sb2st ms quiet -> loaded: %s"
-         % (iters, ", ".join("%d ch ring %d: %.0f -> %.0f" % (nl, ring, tq[(nl, ring)], tn[(nl, ring)]) for nl, ring in cases)))
+         % (iters, ", ".join("%d ch ring %d version %d: %.0f -> %.0f" % (nl, ring, ver, tq[(nl, ring, ver)], tn[(nl, ring, ver)])
+                             for nl, ring, ver in cases)))
     prob.close()
 
 

@@ -207,7 +207,9 @@ def test_sb2sb_to_band16(n, npad, batch):
 
 @pytest.mark.parametrize("n,npad,batch", [(40, 64, 1), (100, 128, 1), (448, 448, 2), (1000, 1024, 2), (2048, 2048, 1)])
 def test_sb2st_two_step(n, npad, batch):
-    """Both steps (sb2st_version 9): band 64 -> 16 -> tridiagonal, eigenvalues of the input; bit-identical when repeated."""
+    """Both steps (sb2st_version 9): band 64 -> 16 -> tridiagonal, eigenvalues of the input; bit-identical when repeated and
+    whoever runs the passes of the second step (rings of workgroups by batch size, one workgroup, pairs, the ABORT and
+    'different XCDs' fallbacks of the handshake)."""
     from scipy.linalg import eigvalsh_tridiagonal
     AB = _random_band64(n, npad, batch, 7 * n)
     old = capi.get_option("sb2st_version")
@@ -215,9 +217,20 @@ def test_sb2st_two_step(n, npad, batch):
     try:
         d, e = capi.stage_sb2st(AB, n)
         d2, e2 = capi.stage_sb2st(AB, n)
+        ring = capi.get_option("sb2st_ring")
+        alone = []
+        for kw in (dict(sb2st_ring=1), dict(sb2st_ring=2), dict(sb2st_force_abort=1), dict(sb2st_force_abort=2)):
+            for k_, v_ in kw.items():
+                capi.set_option(k_, v_)
+            try:
+                alone.append(capi.stage_sb2st(AB, n))
+            finally:
+                capi.set_option("sb2st_ring", ring); capi.set_option("sb2st_force_abort", 0)
     finally:
         capi.set_option("sb2st_version", old)
     assert np.array_equal(d, d2) and np.array_equal(e, e2)
+    for d3, e3 in alone:       # one workgroup per channel, pairs, the two fallbacks of the handshake: the same arithmetic
+        assert np.array_equal(d, d3) and np.array_equal(e, e3)
     for b in range(batch):
         ref = _band_eigs(AB[b], n)
         ev = eigvalsh_tridiagonal(d[b], e[b])
