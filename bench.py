@@ -94,7 +94,7 @@ def profile_summary(channels, nfun):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*final_kernel_stats.csv")), reverse=True):
         try:
             for r in csv.DictReader(open(f)):
-                stats[r["Name"].split("(")[0].replace("void ", "").replace("bsp::", "")] = (float(r["AverageNs"]) * 1e-6, int(r["Calls"]))
+                stats[r["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("bsp::", "")] = (float(r["AverageNs"]) * 1e-6, int(r["Calls"]))
             stats_file = os.path.relpath(f, ROOT)
             break
         except Exception:

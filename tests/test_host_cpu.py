@@ -375,13 +375,18 @@ def test_committed_bench_line_keeps_the_contract():
     F = 4.0 / 3.0 * n ** 3 + 4.0 * n ** 2 * k                        # SURVEY 8(d) flop per l-channel
     assert abs(r["achieved"] - F * d["value"] / 1e12) < 1e-9 * r["achieved"]
     names = [kk["kernel"] for kk in r["kernels"]]
-    assert names[0].startswith("sb2st") and any(x.startswith("gemm2_kernel<128") for x in names) and any(x.startswith("gemm2_kernel<64") for x in names)
+    assert names[0].startswith("sb2sb") and any(x.startswith("gemm2_kernel<128") for x in names) and any(x.startswith("gemm2_kernel<64") for x in names)
     for kk in r["kernels"]:
         assert abs(kk["frac"] - kk["achieved"] / kk["peak"]) < 1e-12
         assert kk["traffic"] is None or (kk["traffic"] > 0 and kk["traffic_source"].startswith("profiles/r02_"))
         assert kk["launch_ms_source"]
-    sb = r["kernels"][0]
-    assert sb["bound"] == "hbm" and sb["traffic"] >= 0.9 * sb["bytes_pass_model"] and sb["bytes_min"] < sb["bytes_pass_model"]
+    sb = r["kernels"][0]                                              # the bulge chasing in two steps: model bytes and PMC bytes agree
+    assert sb["bound"] == "hbm" and sb["bytes_min"] < sb["bytes_model"] == sb["bytes_model_sb2sb"] + sb["bytes_model_sb16st"]
+    assert 0.8 * sb["bytes_model"] <= sb["traffic"] <= 1.2 * sb["bytes_model"]
+    sp = sb["split_from_profile"]
+    assert sp["sb16st_kernel"]["launches_per_step"] == 1 and sp["sb2sb_mfma_kernel"]["launches_per_step"] > 700
+    assert abs(sp["sb2sb_mfma_kernel"]["kernel_ms_per_step"] + sp["sb16st_kernel"]["kernel_ms_per_step"] - sb["launch_ms"]) < 0.05 * sb["launch_ms"]
+    assert r["traffic"] > sb["traffic"]                              # the whole step's HBM bytes
     # value = channels per step / time per step
     assert abs(d["value"] - d["config"]["channels_total"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     c = d["cpu_baseline"]

@@ -8,7 +8,7 @@ import csv, glob, json, sys, collections
 f = glob.glob(sys.argv[1] + "/*counter_collection.csv")[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in csv.DictReader(open(f)):
-    k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
         n[k] += 1

@@ -12,7 +12,7 @@ def per_kernel(d, name):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == name:
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
             agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
     return agg
 

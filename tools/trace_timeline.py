@@ -32,5 +32,5 @@ print("sy2sb window %.1f ms" % (tot / 1e6))
 for k, v in acc.most_common():
     print("  %-10s %7.1f ms  %5.1f %%" % (k, v / 1e6, 100.0 * v / tot))
 per = collections.Counter()
-for s, e, n in win: per[n.split("(")[0][:60]] += e - s
+for s, e, n in win: per[n.replace("(anonymous namespace)::", "").split("(")[0][:60]] += e - s
 for k, v in per.most_common(8): print("  sum %-60s %7.1f ms" % (k, v / 1e6))
