@@ -596,6 +596,15 @@ def test_sizes_beyond_the_build_are_refused_at_create():
     capi.Problem(capi.make_input(kind_grid=0, rb=800.0, k=9, nfun=8256)).close()
 
 
+def test_graft_entry_smoke():
+    """`__graft_entry__.smoke()` is what the driver runs on the GPU before the bench: keep it running (a change of
+    bspatom_assemble's contract once broke its call order without any test noticing)."""
+    import importlib, sys
+    sys.path.insert(0, ROOT)
+    ge = importlib.import_module("__graft_entry__")
+    ge.smoke()
+
+
 def test_unknown_option_is_rejected():
     with pytest.raises(capi.BspAtomError):
         capi.set_option("no_such_switch", 1)
