@@ -703,11 +703,13 @@ __global__ __launch_bounds__(576) void sb16st_kernel(int n, int npad, int batch,
             if (RPn > n) RPn = n;
             if (RPn < RP) RPn = RP;
             if (wv == NW2) {
+                if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime();
                 for (int i = 0; i < 8; ++i) {
                     const int c = RP + 2 * i + mh;
                     double *gp = c < RPn ? AB + (size_t)c * LD + md : dump + lane;
                     *gp = Lw[((c & (WCOLS - 1)) << 5) + md];
                 }
+                if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[0] += t_ - dt0; dt0 = t_; }
                 if ((t & 3) == 0) {
                     for (int i = 0; i < 32; ++i) {
                         const int c = LP + 2 * i + mh;
@@ -729,6 +731,7 @@ __global__ __launch_bounds__(576) void sb16st_kernel(int n, int npad, int batch,
                     }
                 }
             }
+            if (diag && wv == NW2) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[1] += t_ - dt0; }
             if ((t & 3) == 0) LP += 64;
             RP = RPn;
             const int k = t - LAG * wv;
@@ -781,6 +784,13 @@ int launch_sb2sb(int n, int npad, int batch, double *d_AB, hipStream_t st)
         attr = true;
     }
     const bool mf = opts().sb2sb_mfma != 0;
+    if (opts().sb2st_diag) {
+        int nb1 = 0, nb2 = 0;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, reinterpret_cast<const void *>(sb2sb_mfma_kernel), 256, SB2SB2_LDS);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, reinterpret_cast<const void *>(sb2sb_kernel), 256, SB2SB_LDS);
+        fprintf(stderr, "sb2sb: workgroups per CU by the occupancy query: mfma kernel %d (LDS %d B), first kernel %d (LDS %d B)\n", nb1,
+                SB2SB2_LDS, nb2, SB2SB_LDS);
+    }
     const int S = (n - NB1 + NB1 - 1) / NB1;                       // sweeps: j0 + 16 < n
     auto K = [n](int s) { const int m = n - (NB1 * s + NB1); return m > 0 ? (m + B1 - 1) / B1 : 0; };
     int tmax = -1;
@@ -834,8 +844,9 @@ int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double 
         BSP_HIP(hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost));
         hipFree(dbuf);
         for (int w = 0; w < 9; ++w)
-            fprintf(stderr, "sb16st wave %d: %lld steps; s_memtime ticks per step: chase item %.0f, rest + barrier %.0f\n", w, h[w * 5 + 4],
-                    (double)h[w * 5 + 2] / h[w * 5 + 4], (double)h[w * 5 + 3] / h[w * 5 + 4]);
+            fprintf(stderr, "sb16st wave %d: %lld steps; s_memtime ticks per step: chase item %.0f, rest + barrier %.0f (mover wave: columns out %.0f, block in %.0f)\n",
+                    w, h[w * 5 + 4], (double)h[w * 5 + 2] / h[w * 5 + 4], (double)h[w * 5 + 3] / h[w * 5 + 4], (double)h[w * 5] / h[w * 5 + 4],
+                    (double)h[w * 5 + 1] / h[w * 5 + 4]);
         return BSP_OK;
     }
     hipLaunchKernelGGL(sb16st_kernel, dim3(nblk), dim3(576), SB16_LDS, st, n, npad, batch, d_AB, d_d, d_e, (long long *)nullptr,
