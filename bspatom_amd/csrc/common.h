@@ -131,7 +131,8 @@ int launch_extract_band(int npad, int nb, int batch, const double *d_A, double *
 size_t sb2st_ctl_bytes(int batch);
 // two-step route (sbr2.hip): band 64 -> 16 by block bulge chasing, then 16 -> tridiagonal in an LDS window
 int launch_sb2sb(int n, int npad, int batch, double *d_AB, hipStream_t st);
-int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st, int *d_status = nullptr);
+int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st, int *d_status = nullptr,
+                  void *ctl = nullptr);
 int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, double *d_e,
                  hipStream_t st, int *d_status = nullptr, void *ctl = nullptr);
 // tridiag.hip

@@ -1308,7 +1308,7 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
     if (ver == 9) {
         int rc;
         if ((rc = launch_sb2sb(n, npad, batch, d_AB, st))) return rc;
-        return launch_sb16st(n, npad, batch, d_AB, d_d, d_e, st, d_status);
+        return launch_sb16st(n, npad, batch, d_AB, d_d, d_e, st, d_status, ctl);
     }
     if (ver != 3 && ver != 7 && ver != 8) return BSP_ERR_ARG;
     if (ver == 7 || ver == 8) {

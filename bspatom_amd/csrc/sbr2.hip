@@ -16,6 +16,7 @@
 // Band storage as everywhere: AB[d + 128 j] = A(j + d, j) (sy2sb.hip::extract_band_kernel).
 #include "common.h"
 #include <cstdio>
+#include <cstdlib>
 
 namespace bsp {
 namespace {
@@ -689,10 +690,13 @@ __global__ __launch_bounds__(576) void sb16st_kernel(int n, int npad, int batch,
         // leave it with plain stores, 16 per step.  The eight chasing waves never touch global memory inside a pass.
         const int md = lane & 31, mh = lane >> 5;                   // mover lane: row md of columns 2 i + mh
         double qb[32];
+        unsigned long long pw = 0;                                  // the partner's progress word as last seen
         if (wv == NW2) {
+            const unsigned o0 = (unsigned)(LP + mh) * LD + md, omax = (unsigned)(n - 1) * LD;
             for (int i = 0; i < 32; ++i) {                          // unmasked value; the mask is applied at the LDS write
-                const int c = LP + 2 * i + mh;
-                qb[i] = AB[c + md < n ? (size_t)c * LD + md : 0];
+                unsigned o = o0 + 2 * LD * i;
+                o = o < omax ? o : omax;
+                qb[i] = AB[o];
             }
         }
         __syncthreads();
@@ -703,35 +707,50 @@ __global__ __launch_bounds__(576) void sb16st_kernel(int n, int npad, int batch,
             if (RPn > n) RPn = n;
             if (RPn < RP) RPn = RP;
             if (wv == NW2) {
+                // Order matters: everything that WAITS for memory comes first, while the only operations in flight are a step
+                // old; the stores of this step go out last.  (Stores first, as in the first version, made the block's LDS writes
+                // wait for stores issued a moment ago: 5500 ticks every fourth step.)
                 if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime();
-                for (int i = 0; i < 8; ++i) {
-                    const int c = RP + 2 * i + mh;
-                    double *gp = c < RPn ? AB + (size_t)c * LD + md : dump + lane;
-                    *gp = Lw[((c & (WCOLS - 1)) << 5) + md];
-                }
-                if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[0] += t_ - dt0; dt0 = t_; }
                 if ((t & 3) == 0) {
-                    for (int i = 0; i < 32; ++i) {
-                        const int c = LP + 2 * i + mh;
-                        Lw[((c & (WCOLS - 1)) << 5) + md] = c + md < n ? qb[i] : 0.0;
-                    }
-                    if (pubp) {                           // everything stored before this step has reached the L2
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        if (lane == 0)
-                            __hip_atomic_store(pubp, ((unsigned long long)ps << 32) + (unsigned)RP, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if (pollp && ps > 0 && LP + 64 < n) {
+                    if (pollp && ps > 0 && LP + 64 < n) {  // the block about to be requested, as the pass before left it
                         const int need = LP + 128 < n ? LP + 128 : n;
-                        s16_wait(pollp, ((unsigned long long)(ps - 1) << 32) + (unsigned)need, C, status);
+                        const unsigned long long want = ((unsigned long long)(ps - 1) << 32) + (unsigned)need;
+                        if (pw < want) s16_wait(pollp, want, C, status);      // pw was requested two steps ago
+                        else asm volatile("buffer_inv sc1" ::: "memory");
                     }
-                    for (int i = 0; i < 32; ++i) {
-                        const int c = LP + 64 + 2 * i + mh;
-                        qb[i] = AB[c + md < n ? (size_t)c * LD + md : 0];
+                    // 32-bit offsets from uniform bases (one add per element): the data-moving wave is bound by its instructions
+                    {
+                        const unsigned s0_ = (unsigned)(LP + mh), lim = (unsigned)(n - md);      // column c is inside while c < n - md
+                        for (int i = 0; i < 32; ++i) {
+                            const unsigned c = s0_ + 2 * i;
+                            Lw[(((c & (WCOLS - 1)) << 5) + md)] = c < lim ? qb[i] : 0.0;
+                        }
+                        const unsigned o0 = (unsigned)(LP + 64 + mh) * LD + md, omax = (unsigned)(n - 1) * LD;
+                        for (int i = 0; i < 32; ++i) {
+                            unsigned o = o0 + 2 * LD * i;
+                            o = o < omax ? o : omax;                                          // clamped, masked at the LDS write
+                            qb[i] = AB[o];
+                        }
                     }
                 }
+                if ((t & 3) == 3 && pubp) {               // everything stored before this step has reached the L2
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0)
+                        __hip_atomic_store(pubp, ((unsigned long long)ps << 32) + (unsigned)RP, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if ((t & 3) == 2 && pollp) pw = __hip_atomic_load(pollp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[1] += t_ - dt0; dt0 = t_; }
+                {
+                    const unsigned c0_ = (unsigned)(RP + mh), dumpo = (unsigned)npad * LD + 64 + lane;
+                    for (int i = 0; i < 8; ++i) {
+                        const unsigned c = c0_ + 2 * i;
+                        const unsigned o = c < (unsigned)RPn ? c * LD + md : dumpo;
+                        AB[o] = Lw[((c & (WCOLS - 1)) << 5) + md];
+                    }
+                }
+                if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[0] += t_ - dt0; }
             }
-            if (diag && wv == NW2) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[1] += t_ - dt0; }
             if ((t & 3) == 0) LP += 64;
             RP = RPn;
             const int k = t - LAG * wv;
@@ -784,6 +803,14 @@ int launch_sb2sb(int n, int npad, int batch, double *d_AB, hipStream_t st)
         attr = true;
     }
     const bool mf = opts().sb2sb_mfma != 0;
+    static int ldspad = -1;                                 // timing experiment: BSP_SB2SB_LDSPAD=30000 leaves one workgroup per CU
+    if (ldspad < 0) {
+        const char *e = getenv("BSP_SB2SB_LDSPAD");
+        ldspad = e ? atoi(e) : 0;
+        if (ldspad > 0)
+            BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sb2sb_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        SB2SB2_LDS + ldspad));
+    }
     if (opts().sb2st_diag) {
         int nb1 = 0, nb2 = 0;
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, reinterpret_cast<const void *>(sb2sb_mfma_kernel), 256, SB2SB2_LDS);
@@ -802,14 +829,14 @@ int launch_sb2sb(int n, int npad, int batch, double *d_AB, hipStream_t st)
         if (t - LAG * s_hi >= K(s_hi)) continue;
         int s_lo = s_hi;
         while (s_lo > 0 && t - LAG * (s_lo - 1) < K(s_lo - 1)) --s_lo;
-        if (mf) hipLaunchKernelGGL(sb2sb_mfma_kernel, dim3(s_hi - s_lo + 1, batch), dim3(256), SB2SB2_LDS, st, n, npad, d_AB, t, s_lo);
+        if (mf) hipLaunchKernelGGL(sb2sb_mfma_kernel, dim3(s_hi - s_lo + 1, batch), dim3(256), SB2SB2_LDS + ldspad, st, n, npad, d_AB, t, s_lo);
         else hipLaunchKernelGGL(sb2sb_kernel, dim3(s_hi - s_lo + 1, batch), dim3(256), SB2SB_LDS, st, n, npad, d_AB, t, s_lo);
     }
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }
 
-int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st, int *d_status)
+int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st, int *d_status, void *ctl)
 {
     static bool attr = false;
     if (!attr) {
@@ -824,7 +851,12 @@ int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double 
     static Sb16Ctl *s_ctl = nullptr;
     static int cap = 0;
     Sb16Ctl *d_ctl = nullptr;
-    if (P > 1) {
+    static_assert(sizeof(Sb16Ctl) <= 112, "the caller's per-problem control block is sized for sb2st.hip's Sb8Ctl (112 bytes per channel)");
+    if (P > 1 && ctl) {                                     // the problem's own control block (capi.hip: PipeBufs::sbctl)
+        d_ctl = static_cast<Sb16Ctl *>(ctl);
+        BSP_HIP(hipMemsetAsync(d_ctl, 0, (size_t)batch * sizeof(Sb16Ctl), st));
+    }
+    else if (P > 1) {
         if (cap < batch) {
             if (s_ctl) hipFree(s_ctl);
             BSP_HIP(hipMalloc(reinterpret_cast<void **>(&s_ctl), (size_t)batch * sizeof(Sb16Ctl)));
