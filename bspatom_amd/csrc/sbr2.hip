@@ -279,25 +279,29 @@ __global__ __launch_bounds__(256) void sb2sb_mfma_kernel(int n, int npad, double
     const int ncl = k == 0 ? NB1 : B1;
     const int gi = r0 + lane;
 
-    // ---- panel into registers (and the rest of the left tile into X)
-    double xc[4];
+    // ---- every load of the first two tiles is requested before anything waits: the panel (needed at once), the rest of the left
+    // tile (needed after the QR), the diagonal tile (after the left tile); rows beyond n read row r0 and are masked at use
+    const bool rin = gi < n;
+    const int gr = rin ? gi : r0;
+    double xc[4], lt[12], pf[16];
     for (int q = 0; q < 4; ++q) {
         const int gc = pc0 + w + 4 * q;
-        xc[q] = gi < n ? AB[(size_t)gc * LD + (gi - gc)] : 0.0;
+        xc[q] = AB[(size_t)gc * LD + (gr - gc)];
     }
-    if (k > 0)
-        for (int c = 16 + w; c < 64; c += 4) {
-            const int gc = pc0 + c;
-            X[c * XLD + lane] = gi < n ? AB[(size_t)gc * LD + (gi - gc)] : 0.0;
+    if (k > 0) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const int gc = pc0 + 16 + w + 4 * q;
+            lt[q] = AB[(size_t)gc * LD + (gr - gc)];
         }
-    // the diagonal tile is requested now and waited for after the QR; the next bulge tile before the diagonal tile's products
-    double pf[16];
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int c = w + 4 * q;                          // column c, rows lane >= c (clamped address, masked at use)
-        const bool in = lane >= c && gi < n;
+        const bool in = lane >= c && rin;
         pf[q] = AB[in ? (size_t)(r0 + c) * LD + (lane - c) : 0];
     }
+    for (int q = 0; q < 4; ++q) xc[q] = rin ? xc[q] : 0.0;
 #pragma unroll
     for (int i = 0; i < NB1; ++i) {
         if (w == (i & 3)) {
@@ -326,6 +330,10 @@ __global__ __launch_bounds__(256) void sb2sb_mfma_kernel(int n, int npad, double
     for (int q = 0; q < 4; ++q) {                          // R (and zeros) back to the band
         const int gc = pc0 + w + 4 * q;
         if (gi < n) AB[(size_t)gc * LD + (gi - gc)] = xc[q];
+    }
+    if (k > 0) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) X[(16 + w + 4 * q) * XLD + lane] = rin ? lt[q] : 0.0;
     }
     // G = V^T V, split over the waves along the rows
     {
