@@ -424,3 +424,35 @@ def test_fortran_g_with_exponent_width():
     assert fortran_g(-2.5e12, 20, 10, 3) == "  -0.2500000000E+013"
     assert fortran_g(0.0, 20, 10, 3) == "    0.000000000     "
     assert fortran_g(0.25, 20, 10) == "    0.2500000000    "
+
+
+def test_two_step_band_reduction_prototype():
+    """tools/proto_sbr.py is the dense NumPy statement of what csrc/sbr2.hip does (block bulge chasing 64 -> 16 in wavefront order
+    with a lag of 3 between sweeps, then the one-column chase 16 -> 1): the wavefront order never runs two items with overlapping
+    tiles, the working band stays inside the 128 rows per column of the band array, the result has half-width 16 resp. 1, the
+    eigenvalues survive -- and a lag of 2 does produce overlapping tiles (the kernels' LAG = 3 is not arbitrary)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("proto_sbr", os.path.join(ROOT, "tools", "proto_sbr.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    import numpy as np
+    n = 320
+    rng = np.random.default_rng(3)
+    A = np.zeros((n, n))
+    for d in range(m.B + 1):
+        v = rng.standard_normal(n - d)
+        A += np.diag(v, -d) + (np.diag(v, d) if d else 0)
+    ev0 = np.linalg.eigvalsh(A)
+    st = m.sb2sb(A)
+    assert st["max_bw"] <= 2 * m.B - 1 and m.bandwidth(A, 1e-13 * np.max(np.abs(ev0))) == m.D
+    assert np.max(np.abs(np.linalg.eigvalsh(A) - ev0)) <= 1e-13 * np.max(np.abs(ev0))
+    A16 = np.triu(np.tril(A, m.D), -m.D)
+    m.chase_to_tridiagonal(A16, m.D)
+    T = np.triu(np.tril(A16, 1), -1)
+    assert m.bandwidth(A16, 1e-13 * np.max(np.abs(ev0))) == 1
+    assert np.max(np.abs(np.linalg.eigvalsh(T) - ev0)) <= 1e-13 * np.max(np.abs(ev0))
+    m.LAG = 2
+    try:
+        with pytest.raises(AssertionError):
+            m.sb2sb(np.array(A16 + 0.0) * 0 + np.triu(np.tril(rng.standard_normal((n, n)), m.B), -m.B))
+    finally:
+        m.LAG = 3
