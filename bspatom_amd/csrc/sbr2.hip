@@ -470,258 +470,6 @@ __global__ __launch_bounds__(256) void sb2sb_mfma_kernel(int n, int npad, double
         if (gi1 < n) AB[(size_t)gc * LD + (gi1 - gc)] = X[c * XLD + lane];
     }
 }
-// The same with half tiles in LDS (32 columns of a tile at a time, every K loop in the same order: bit-identical results): 54 KB
-// instead of 70 KB of LDS, THREE workgroups per CU.
-constexpr int SB2SB3_LDS = (32 * XLD + 4 * 64 * VLD + 16 * VLD + 16) * 8;
-__global__ __launch_bounds__(256, 3) void sb2sb_mfma3_kernel(int n, int npad, double *__restrict__ ABall, int t, int s_lo)
-{
-    extern __shared__ double lds[];
-    double *X = lds, *V = X + 32 * XLD, *VT = V + 64 * VLD, *Yb = VT + 64 * VLD, *Z = Yb + 64 * VLD, *G = Z + 64 * VLD,
-           *tau = G + 16 * VLD;
-    double *Gp = Z;                                       // split-K partials [4][16 x VLD] live where Z is not yet
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-    const int s = s_lo + blockIdx.x, k = t - LAG * s;
-    if (k < 0) return;
-    const int j0 = NB1 * s, r0 = j0 + NB1 + B1 * k;
-    if (r0 >= n) return;
-    double *AB = ABall + blockIdx.y * ab_stride(npad);
-    const int pc0 = k == 0 ? j0 : r0 - B1;
-    const int ncl = k == 0 ? NB1 : B1;
-    const int gi = r0 + lane;
-
-    // ---- every load of the first two tiles is requested before anything waits: the panel (needed at once), the rest of the left
-    // tile (needed after the QR), the diagonal tile (after the left tile); rows beyond n read row r0 and are masked at use
-    const bool rin = gi < n;
-    const int gr = rin ? gi : r0;
-    double xc[4], lt[12], pf[16];
-    for (int q = 0; q < 4; ++q) {
-        const int gc = pc0 + w + 4 * q;
-        xc[q] = AB[(size_t)gc * LD + (gr - gc)];
-    }
-    if (k > 0) {
-#pragma unroll
-        for (int q = 0; q < 12; ++q) {
-            const int gc = pc0 + 16 + w + 4 * q;
-            lt[q] = AB[(size_t)gc * LD + (gr - gc)];
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int c = w + 4 * q;                          // column c, rows lane >= c (clamped address, masked at use)
-        const bool in = lane >= c && rin;
-        pf[q] = AB[in ? (size_t)(r0 + c) * LD + (lane - c) : 0];
-    }
-    for (int q = 0; q < 4; ++q) xc[q] = rin ? xc[q] : 0.0;
-#pragma unroll
-    for (int i = 0; i < NB1; ++i) {
-        if (w == (i & 3)) {
-            const double x = xc[i >> 2];
-            const double nrm2 = wsum_dpp(lane > i ? x * x : 0.0);
-            const double alpha = rlane(x, i);
-            double tq = 0.0, scale = 0.0, beta = alpha;
-            if (nrm2 != 0.0) {
-                beta = -copysign(sqrt(alpha * alpha + nrm2), alpha);
-                tq = (beta - alpha) / beta;
-                scale = 1.0 / (alpha - beta);
-            }
-            V[lane * VLD + i] = lane < i ? 0.0 : (lane == i ? 1.0 : x * scale);
-            if (lane == 0) tau[i] = tq;
-            xc[i >> 2] = lane < i ? x : (lane == i ? beta : 0.0);
-        }
-        lds_bar();
-        const double v = V[lane * VLD + i], tq = tau[i];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (w + 4 * q > i) {
-                const double dot = wsum_dpp(v * xc[q]);
-                xc[q] -= tq * dot * v;
-            }
-    }
-    for (int q = 0; q < 4; ++q) {                          // R (and zeros) back to the band
-        const int gc = pc0 + w + 4 * q;
-        if (gi < n) AB[(size_t)gc * LD + (gi - gc)] = xc[q];
-    }
-    // G = V^T V, split over the waves along the rows
-    {
-        d4_t acc = {0.0, 0.0, 0.0, 0.0};
-        for (int q = 0; q < 4; ++q) {
-            const double a = V[(16 * w + 4 * q + l4) * VLD + l15];
-            acc = MFMA(a, a, acc);
-        }
-        for (int r = 0; r < 4; ++r) Gp[w * 16 * VLD + (l4 + 4 * r) * VLD + l15] = acc[r];
-    }
-    lds_bar();
-    {
-        const int i = tid >> 4, j = tid & 15, o = i * VLD + j;
-        G[o] = (Gp[o] + Gp[16 * VLD + o]) + (Gp[32 * VLD + o] + Gp[48 * VLD + o]);
-    }
-    lds_bar();
-    if (w == 0) {                                         // VT T^-1 = V, row by row
-        double vt[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            double a = V[lane * VLD + j];
-#pragma unroll
-            for (int i = 0; i < j; ++i) a -= vt[i] * G[i * VLD + j];
-            vt[j] = a * tau[j];
-            VT[lane * VLD + j] = vt[j];
-        }
-    }
-    lds_bar();
-
-    // ---- left tile, 32 columns at a time (tile columns 16..47, then 48..63)
-    if (k > 0) {
-#pragma unroll
-        for (int rnd = 0; rnd < 2; ++rnd) {
-            const int nblk = rnd == 0 ? 2 : 1, q0 = rnd == 0 ? 0 : 8, nq = rnd == 0 ? 8 : 4;
-#pragma unroll
-            for (int q = 0; q < nq; ++q) X[(w + 4 * q) * XLD + lane] = rin ? lt[q0 + q] : 0.0;
-            lds_bar();
-            if (w < nblk) {                               // W2 = VT^T X(:, block w of this round)
-                d4_t acc = {0.0, 0.0, 0.0, 0.0};
-                const int cn = 16 * w + l15;
-                for (int q = 0; q < 16; ++q) acc = MFMA(VT[(4 * q + l4) * VLD + l15], X[cn * XLD + 4 * q + l4], acc);
-                for (int r = 0; r < 4; ++r) Yb[(l4 + 4 * r) * XLD + cn] = acc[r];
-            }
-            lds_bar();
-            for (int nb = 0; nb < nblk; ++nb) {            // X -= V W2, row block w
-                const int cn = 16 * nb + l15;
-                d4_t acc;
-                for (int r = 0; r < 4; ++r) acc[r] = X[cn * XLD + 16 * w + l4 + 4 * r];
-                for (int q = 0; q < 4; ++q) acc = MFMA(-V[(16 * w + l15) * VLD + 4 * q + l4], Yb[(4 * q + l4) * XLD + cn], acc);
-                for (int r = 0; r < 4; ++r) X[cn * XLD + 16 * w + l4 + 4 * r] = acc[r];
-            }
-            lds_bar();
-#pragma unroll
-            for (int q = 0; q < nq; ++q) {
-                const int gc = pc0 + 16 + w + 4 * (q0 + q);
-                if (gi < n) AB[(size_t)gc * LD + (gi - gc)] = X[(w + 4 * q) * XLD + lane];
-            }
-            lds_bar();
-        }
-    }
-
-    // ---- diagonal tile: Y = D VT accumulated over the two column halves of D
-    const int r1 = r0 + B1, gi1 = r1 + lane;
-    const bool more = r1 < n;
-    double pfb[16];
-    if (more) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int gc = r0 + w + 4 * q;
-            pfb[q] = AB[gi1 < n ? (size_t)gc * LD + (gi1 - gc) : 0];
-        }
-    }
-    auto fill_D = [&](int h) {                            // columns 32 h .. 32 h + 31 of the symmetric tile, all 64 rows
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int c = w + 4 * q;
-            if (lane >= c) {
-                const double v = gi < n ? pf[q] : 0.0;
-                if ((c >> 5) == h) X[(c & 31) * XLD + lane] = v;
-                if ((lane >> 5) == h) X[(lane & 31) * XLD + c] = v;
-            }
-        }
-    };
-    {
-        d4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (h) lds_bar();
-            fill_D(h);
-            lds_bar();
-            for (int q = 0; q < 8; ++q)
-                acc = MFMA(X[(4 * q + l4) * XLD + 16 * w + l15], VT[(4 * (8 * h + q) + l4) * VLD + l15], acc);
-        }
-        for (int r = 0; r < 4; ++r) Yb[(16 * w + l4 + 4 * r) * VLD + l15] = acc[r];
-    }
-    lds_bar();
-    {                                                     // M = VT^T Y, split along the rows
-        d4_t acc = {0.0, 0.0, 0.0, 0.0};
-        for (int q = 4 * w; q < 4 * w + 4; ++q) acc = MFMA(VT[(4 * q + l4) * VLD + l15], Yb[(4 * q + l4) * VLD + l15], acc);
-        for (int r = 0; r < 4; ++r) Gp[w * 16 * VLD + (l4 + 4 * r) * VLD + l15] = acc[r];
-    }
-    lds_bar();
-    {
-        const int i = tid >> 4, j = tid & 15, o = i * VLD + j;
-        G[o] = (Gp[o] + Gp[16 * VLD + o]) + (Gp[32 * VLD + o] + Gp[48 * VLD + o]);
-    }
-    lds_bar();
-    {                                                     // Z = Y - 1/2 V M, row block w
-        d4_t acc;
-        for (int r = 0; r < 4; ++r) acc[r] = Yb[(16 * w + l4 + 4 * r) * VLD + l15];
-        for (int q = 0; q < 4; ++q) acc = MFMA(-0.5 * V[(16 * w + l15) * VLD + 4 * q + l4], G[(4 * q + l4) * VLD + l15], acc);
-        for (int r = 0; r < 4; ++r) Z[(16 * w + l4 + 4 * r) * VLD + l15] = acc[r];
-    }
-    lds_bar();
-    // D -= V Z^T + Z V^T: the half that is in X (columns 32..63) first, then columns 0..31 again
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        const int h = 1 - hh;
-        if (hh) { fill_D(0); lds_bar(); }
-        const int nblocks = h ? 3 : 7;                    // lower blocks (mb, nb) with nb in this half
-        for (int bi = w; bi < nblocks; bi += 4) {
-            int mb, nb;
-            if (h) { mb = bi == 0 ? 2 : 3; nb = bi == 2 ? 3 : 2; }
-            else { mb = bi == 0 ? 0 : (bi < 3 ? 1 : (bi < 5 ? 2 : 3)); nb = (bi == 2 || bi == 4 || bi == 6) ? 1 : 0; }
-            const int cb = 16 * (nb & 1) + l15;           // column inside the half
-            d4_t acc;
-            for (int r = 0; r < 4; ++r) acc[r] = X[cb * XLD + 16 * mb + l4 + 4 * r];
-            for (int q = 0; q < 4; ++q) {
-                acc = MFMA(-V[(16 * mb + l15) * VLD + 4 * q + l4], Z[(16 * nb + l15) * VLD + 4 * q + l4], acc);
-                acc = MFMA(-Z[(16 * mb + l15) * VLD + 4 * q + l4], V[(16 * nb + l15) * VLD + 4 * q + l4], acc);
-            }
-            for (int r = 0; r < 4; ++r) X[cb * XLD + 16 * mb + l4 + 4 * r] = acc[r];
-        }
-        lds_bar();
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int c = 32 * h + w + 4 * q;
-            if (lane >= c && gi < n) AB[(size_t)(r0 + c) * LD + (lane - c)] = X[(c & 31) * XLD + lane];
-        }
-        lds_bar();
-    }
-
-    // ---- next bulge tile: W1 = X' VT over the two halves, then X' -= W1 V^T half by half
-    if (!more) return;
-    {
-        d4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (h) lds_bar();
-#pragma unroll
-            for (int q = 0; q < 8; ++q) X[(w + 4 * q) * XLD + lane] = gi1 < n ? pfb[8 * h + q] : 0.0;
-            lds_bar();
-            for (int q = 0; q < 8; ++q)
-                acc = MFMA(X[(4 * q + l4) * XLD + 16 * w + l15], VT[(4 * (8 * h + q) + l4) * VLD + l15], acc);
-        }
-        for (int r = 0; r < 4; ++r) Yb[(16 * w + l4 + 4 * r) * VLD + l15] = acc[r];
-    }
-    lds_bar();
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        const int h = 1 - hh;
-        if (hh) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) X[(w + 4 * q) * XLD + lane] = gi1 < n ? pfb[q] : 0.0;
-            lds_bar();
-        }
-        for (int nb2 = 0; nb2 < 2; ++nb2) {
-            const int nb = 2 * h + nb2, cb = 16 * nb2 + l15;
-            d4_t acc;
-            for (int r = 0; r < 4; ++r) acc[r] = X[cb * XLD + 16 * w + l4 + 4 * r];
-            for (int q = 0; q < 4; ++q) acc = MFMA(-Yb[(16 * w + l15) * VLD + 4 * q + l4], V[(16 * nb + l15) * VLD + 4 * q + l4], acc);
-            for (int r = 0; r < 4; ++r) X[cb * XLD + 16 * w + l4 + 4 * r] = acc[r];
-        }
-        lds_bar();
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int gc = r0 + 32 * h + w + 4 * q;
-            if (gi1 < n) AB[(size_t)gc * LD + (gi1 - gc)] = X[(w + 4 * q) * XLD + lane];
-        }
-        lds_bar();
-    }
-}
 #undef MFMA
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1060,8 +808,6 @@ int launch_sb2sb(int n, int npad, int batch, double *d_AB, hipStream_t st)
                                     SB2SB_LDS));
         BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sb2sb_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     SB2SB2_LDS));
-        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sb2sb_mfma3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    SB2SB3_LDS));
         attr = true;
     }
     const int mf = opts().sb2sb_mfma;
@@ -1091,8 +837,7 @@ int launch_sb2sb(int n, int npad, int batch, double *d_AB, hipStream_t st)
         if (t - LAG * s_hi >= K(s_hi)) continue;
         int s_lo = s_hi;
         while (s_lo > 0 && t - LAG * (s_lo - 1) < K(s_lo - 1)) --s_lo;
-        if (mf == 3) hipLaunchKernelGGL(sb2sb_mfma3_kernel, dim3(s_hi - s_lo + 1, batch), dim3(256), SB2SB3_LDS, st, n, npad, d_AB, t, s_lo);
-        else if (mf) hipLaunchKernelGGL(sb2sb_mfma_kernel, dim3(s_hi - s_lo + 1, batch), dim3(256), SB2SB2_LDS + ldspad, st, n, npad, d_AB, t, s_lo);
+        if (mf) hipLaunchKernelGGL(sb2sb_mfma_kernel, dim3(s_hi - s_lo + 1, batch), dim3(256), SB2SB2_LDS + ldspad, st, n, npad, d_AB, t, s_lo);
         else hipLaunchKernelGGL(sb2sb_kernel, dim3(s_hi - s_lo + 1, batch), dim3(256), SB2SB_LDS, st, n, npad, d_AB, t, s_lo);
     }
     BSP_HIP(hipGetLastError());
