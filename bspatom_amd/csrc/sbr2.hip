@@ -1,17 +1,20 @@
-// sbr2.hip -- the bulge chasing in TWO steps (BSP_SB2ST_VERSION=9): band 64 -> band 16 -> tridiagonal.
+// sbr2.hip -- the bulge chasing in TWO steps: band 64 -> band 16 -> tridiagonal.  The default for n >= 512
+// (BSP_SB2ST_VERSION=0 / 9; sb2st.hip, the one-step chase, below that and as the cross-check).
 //
 // Replaces DSYTRD's second half inside DSYGV (reference call site matrices.f90:248) like sb2st.hip does; the reason for a
 // second route is bytes: a one-column-at-a-time chase of a band of half-width b re-reads and re-writes the band once per
-// sweep (or per two sweeps, sb2st.hip v7/v8): 6 n^2 b bytes per channel, 825 GB per 128-channel step at b = 64.  Here
-//   step 1 (sb2sb_kernel): BLOCK bulge chasing (Bischof/Lang/Sun's SBR scheme).  A sweep takes 16 columns at once: QR of a
-//          64 x 16 block, the block reflector Q = I - V T V^T applied to three 64 x 64 tiles per chase item -- the same tiles a
-//          column sweep touches, 16 times less often.  Items (sweep s, step k) with k + 3 s = t are independent (their tile
-//          sets are disjoint, tools/proto_sbr.py checks it), so ONE LAUNCH PER WAVEFRONT t orders everything: no flags, no
-//          spinning, bit-identical results by construction.
-//   step 2 (sb16st_kernel): one-column chase of the band of half-width 16, ONE workgroup per channel: its 8 waves run 8
-//          consecutive sweeps, three items apart, on a sliding window of the band held in LDS (512 columns x 32 rows:
-//          the band and what the sweeps leave of their bulges, which stays in the matrix between passes);
-//          HBM sees each pass of 8 sweeps once.
+// sweep (or per two sweeps, sb2st.hip v7/v8): 6 n^2 b bytes per channel, 936 GB measured per 128-channel step at b = 64
+// against 255 GB here.
+//   step 1 (sb2sb_mfma_kernel; sb2sb_kernel = the first, all-VALU version, kept as its cross-check): BLOCK bulge chasing
+//          (Bischof/Lang/Sun's SBR scheme).  A sweep takes 16 columns at once: QR of a 64 x 16 block, the block reflector
+//          Q = I - V T V^T applied to three 64 x 64 tiles per chase item -- the same tiles a column sweep touches, 16 times
+//          less often.  Items (sweep s, step k) with k + 3 s = t are independent (their tile sets are disjoint,
+//          tools/proto_sbr.py checks it), so ONE LAUNCH PER WAVEFRONT t orders everything: no flags, no spinning,
+//          bit-identical results by construction.
+//   step 2 (sb16st_kernel): one-column chase of the band of half-width 16.  A workgroup = 8 chasing waves (8 consecutive
+//          sweeps, three items apart) + one wave that only moves data, on a sliding window of the band held in LDS (512
+//          columns x 32 rows: the band and what the sweeps leave of their bulges, which stays in the matrix between
+//          passes); HBM sees each pass of 8 sweeps once.  P = 1 .. 8 workgroups share the passes of a channel (Sb16Ctl).
 // Index conventions, the lag of 3 and the working band (<= 127 / <= 31 sub-diagonals) are those of tools/proto_sbr.py.
 // Band storage as everywhere: AB[d + 128 j] = A(j + d, j) (sy2sb.hip::extract_band_kernel).
 #include "common.h"
