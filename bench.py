@@ -6,22 +6,31 @@ One "step" = one pass of the hot path over one batch of l-channels per GPU, inpu
   (all nfun eigenvalues of every channel) + the (l_ini, n0_ini) eigenvector and its WRITE_WF table
   on the rank that owns l_ini + the RCCL all-gather of the spectra.
 Workload (BASELINE configs[3], "Hydrogen l=0..127, N_bsp=4096"): KIND_GRID=0 ra=0 rb=800 k=9
-nfun=4096 Zatom=1.  --scaling weak (default): every GPU solves `--channels` (128) consecutive l-channels, rank r
-takes l = r*channels .. (r+1)*channels-1 (cost per channel does not depend on l); --scaling strong: configs[3] as
-stated, 128 channels in total, 128/N per GPU.  The shards come from bspatom_amd/parallel.py (channel_range,
-gather_spectra -- the code the gloo world-size-2 tests cover); no data-path collective except the final gather.
+nfun=4096 Zatom=1.  The l-loop being sharded is reference matrices.f90:242-248.
 
-  python bench.py --gpus 1 --steps 3 --warmup 1
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant stage,
-HIP-event time measured live on the library's stream) and `cpu_baseline` (the compiled reference
-oracle/_ref/ref_dump.x when present, else the CPU oracle port) objects.
+N = 1 runs in this process.  N > 1 without RANK in the environment: this process starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+as a CHILD (subprocess, before anything here has touched a GPU or imported torch), relays the child's one JSON
+line and exits with its code.  Under a launcher (RANK set) every rank runs `run()`.
+
+`value` (scaling "weak"): every GPU solves `--channels` (128) consecutive l-channels, rank r takes
+l = r*channels .. (r+1)*channels-1 (cost per channel does not depend on l).  At N > 1 the line also carries
+`configs3_as_stated`: BASELINE configs[3] exactly as written -- 128 channels in total, 128/N per GPU -- measured in the
+same run (K more steps after the timed region of `value`, same barrier / max-over-ranks bracket).  `--scaling strong`
+makes that figure `value` instead.  The shards come from bspatom_amd/parallel.py (channel_range, gather_spectra -- the
+code the gloo world-size-2 tests cover); no data-path collective except the final gather.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (whole path against the fp64 peak; per
+kernel: launch durations measured in THIS run with HIP events around every launch, in one extra untimed step) and
+`cpu_baseline` (the compiled reference oracle/_ref/ref_dump.x when present, else the CPU oracle port).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -73,41 +82,364 @@ def cpu_baseline(sample_nfun, k):
             "value_scaled_to_nfun4096": (1.0 / t) * (sample_nfun / 4096.0) ** 3}
 
 
-def profile_summary(channels, nfun):
-    """The newest committed PMC summary for this workload (profiles/*_pmc_summary.json, written by
-    tools/pmc_summary.py from two separate rocprofv3 --pmc passes: FETCH_SIZE x2 gfx950 correction, WRITE_SIZE exact)
-    and kernel-stats file (profiles/*_kernel_stats.csv, rocprofv3 --kernel-trace --stats of this same command).
-    rocprofv3 cannot run inside this process: these are COMMITTED PROFILES, named in the line, not measurements of
-    this run.  Returns (pmc dict or None, pmc file, {kernel: avg ms}, stats file)."""
-    import csv
+def kernel_sources_sha():
+    """sha256 over the kernel sources (csrc/*.hip, common.h): committed counter profiles carry it (profiles/*.json,
+    key "csrc_sha16") so that a profile taken with other kernels is recognised as stale."""
     import glob
-    pmc, pmc_file = None, None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
-        try:
-            d = json.load(open(f))
-        except Exception:
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "bspatom_amd", "csrc", "*.hip")) + [os.path.join(ROOT, "bspatom_amd", "csrc", "common.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_summary(channels, nfun):
+    """The newest committed counter profiles for this workload: profiles/*_pmc_summary.json (tools/pmc_summary.py: two separate
+    rocprofv3 --pmc passes, FETCH_SIZE x2 gfx950 correction, WRITE_SIZE exact) and profiles/*_mfma_util.json (MFMA pipe busy,
+    kernel alone).  rocprofv3 cannot run inside this process: these are COMMITTED PROFILES, named in the line, and flagged
+    `stale` when their csrc_sha16 is not the hash of the kernel sources this run was built from.  Kernel DURATIONS do not
+    come from here: they are measured live (bspatom_kernel_times)."""
+    import glob
+    sha = kernel_sources_sha()
+
+    def newest(pat, ok):
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pat)), reverse=True):
+            try:
+                d = json.load(open(f))
+            except Exception:
+                continue
+            if ok(d):
+                return d, os.path.relpath(f, ROOT), d.get("csrc_sha16") != sha
+        return None, None, None
+    pmc, pmc_file, pmc_stale = newest("*_pmc_summary.json", lambda d: d.get("workload", {}).get("channels") == channels and
+                                      d.get("workload", {}).get("nfun") == nfun)
+    mf, mf_file, mf_stale = newest("*_mfma_util.json", lambda d: "kernels" in d)
+    for f, st in ((pmc_file, pmc_stale), (mf_file, mf_stale)):
+        if f and st:
+            sys.stderr.write("bench: committed profile %s was taken with other kernel sources (csrc_sha16 differs): its "
+                             "figures are marked stale in the line; re-run tools/gpu_profiles.sh\n" % f)
+    return pmc, pmc_file, pmc_stale, ({k.replace("bsp::", ""): v for k, v in mf["kernels"].items()} if mf else {}), mf_file, mf_stale
+
+
+def syr2k_tiles(npad):
+    """128 x 128 tiles the rank-128 update executes per channel, summed over the panels (gemm_f64.hip::syr2k_lower_f64:
+    row block bx holds column blocks 0 .. min(bx + 1, nb - 1))."""
+    tiles = 0
+    for p in range(npad // 64 - 1):
+        m = npad - (p + 1) * 64
+        nb = (m + 127) // 128
+        tiles += sum(min(bx + 1, nb - 1) + 1 for bx in range(nb))
+    return tiles
+
+
+def symm_tiles(npad):
+    """(row tiles of 128, K) pairs of symm per channel: sum over panels of ceil(m/128) * m."""
+    return sum(((npad - (p + 1) * 64 + 127) // 128) * (npad - (p + 1) * 64) for p in range(npad // 64 - 1))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args, argv):
+    """--gpus N > 1 and no launcher around us: start the N ranks as a child `torch.distributed.run` (never exec, and
+    nothing in this process has touched the GPU: torch is not even imported), relay its JSON line, return its code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.stderr.write("bench: starting %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+    out, _ = p.communicate()
+    lines = [l for l in out.split("\n") if l.startswith("{")]
+    for l in out.split("\n"):
+        if l and not l.startswith("{"):
+            sys.stderr.write(l + "\n")           # launcher chatter does not belong on the one-line stdout
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    if p.returncode == 0 and len(lines) != 1:
+        sys.stderr.write("bench: expected one JSON line from the ranks, got %d\n" % len(lines))
+        return 1
+    return p.returncode
+
+
+def run(args):
+    selftest = args.selftest_launcher
+    import torch                      # first: its HIP runtime is the one the process uses
+    import torch.distributed as dist
+    import numpy as np
+    from bspatom_amd import parallel
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench: --gpus %d but WORLD_SIZE %d (start the ranks with --nproc-per-node %d, or run "
+                         "`python bench.py --gpus %d` without a launcher and let it start them)" % (args.gpus, world, args.gpus, args.gpus))
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # launched by torch.distributed.run (also at N=1)
+    if selftest:
+        # CPU rehearsal of the launch path (tests/test_host_cpu.py): gloo, no GPU, no solve -- the spectra are stand-ins that
+        # encode (channel, index); everything else (sharding, gather, barrier bracket, max over ranks, one line) is the real code
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: libbspatom has no CPU path")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    # rank 0 prints ONE line on stdout: RCCL writes its banner (version, hostname, library path) to stdout when the
+    # communicator is created, so everything but the result line goes to stderr
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if selftest:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
+
+    def shard(mode):
+        if mode == "weak":
+            total = world * args.channels
+            cnts = [parallel.channel_range(r, world, total - 1, per_rank=args.channels)[1] for r in range(world)]
+            l0_, nl_ = parallel.channel_range(rank, world, total - 1, per_rank=args.channels)
+        else:
+            total = args.channels
+            cnts = [parallel.channel_range(r, world, total - 1)[1] for r in range(world)]
+            l0_, nl_ = parallel.channel_range(rank, world, total - 1)
+        return total, cnts, l0_, nl_
+
+    modes = [args.scaling] + ([m for m in ("weak", "strong") if m != args.scaling] if world > 1 else [])
+    l_ini = 0
+    total_max = max(shard(m)[0] for m in modes)
+    if selftest:
+        prob, n = None, args.nfun
+    else:
+        from bspatom_amd import capi
+        inp = capi.make_input(kind_grid=0, ra=0.0, rb=args.rb, k=args.k, nfun=args.nfun, n0_ini=1, l_ini=l_ini,
+                              l_fin=total_max - 1, zatom=1.0)
+        prob = capi.Problem(inp, device=local)
+        n = prob.nfun
+    E_dev = torch.empty(max(max(shard(m)[3] for m in modes), 1) * n, dtype=torch.float64, device=dev)
+
+    def sync():
+        if use_dist:
+            dist.barrier()
+        if not selftest:
+            torch.cuda.synchronize()
+
+    def measure(mode, steps, warmup):
+        """W untimed + K timed steps of one sharding; returns the per-mode record (rank 0 keeps E_all for the checks)."""
+        total, counts, l0, nl = shard(mode)
+        owner = next(r for r in range(world) if sum(counts[:r]) <= l_ini < sum(counts[:r + 1]))
+        stage_ms = np.zeros(6)
+        state = {"E_all": None}
+
+        def step(timed):
+            if nl > 0 and not selftest:
+                info = prob.solve_dev(l0, nl, E_dev.data_ptr())      # returns when the library's stream has drained
+                assert (info == 0).all()
+                if timed:
+                    t = prob.last_timing()
+                    stage_ms[:] += [t["assemble"], t["chol_std"], t["sy2sb"], t["sb2st"], t["bisect"], t["total"]]
+            elif nl > 0:
+                E_dev[: nl * n] = (torch.arange(l0, l0 + nl, dtype=torch.float64).repeat_interleave(n) * 1e6 +
+                                   torch.arange(n, dtype=torch.float64).repeat(nl))
+            if rank == owner and not selftest:     # owner of l_ini: the one eigenvector KIND_PI=0 consumes + WRITE_WF
+                c = prob.eigvec(l_ini, 1)
+                prob.write_wf(c)
+            # all-gather of the spectra: the only collective of the path (RCCL; at N = 1 under a launcher too).  E_dev is
+            # rewritten by the next solve on the library's own stream, so the gather must have completed before the step ends.
+            state["E_all"] = parallel.gather_spectra(E_dev[: nl * n], n, counts)
+            if use_dist and not selftest:
+                torch.cuda.current_stream().synchronize()
+
+        for _ in range(warmup):
+            step(False)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(True)
+        sync()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return {"mode": mode, "total": total, "counts": counts, "l0": l0, "nl": nl, "owner": owner, "dt": dt,
+                "stage_ms": stage_ms / max(steps, 1), "E_all": state["E_all"],
+                "value": total * steps / dt, "ms_per_step": 1e3 * dt / steps}
+
+    recs = [measure(m, args.steps, args.warmup) for m in modes]
+    main = recs[0]
+    total, counts, nl = main["total"], main["counts"], main["nl"]
+
+    # one more, UNTIMED step of the main sharding with HIP events around every launch of the big kernels (option "ktime")
+    ktimes = None
+    if not selftest and nl > 0:
+        capi.set_option("ktime", 1)
+        prob.solve_dev(main["l0"], nl, E_dev.data_ptr())
+        ktimes = capi.kernel_times()
+        capi.set_option("ktime", 0)
+        kstage = prob.last_timing()
+    sync()
+
+    if rank == 0:
+        out = {"metric": "l-channel eigensolves/sec at N_bsp=%d fp64" % n, "value": main["value"], "unit": "eigensolves/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main["ms_per_step"],
+               "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+        for rec in recs:
+            E_all = rec["E_all"]
+            assert tuple(E_all.shape) == (rec["total"], n), (tuple(E_all.shape), rec["total"], n)
+            if selftest:
+                want = (torch.arange(rec["total"], dtype=torch.float64)[:, None] * 1e6 + torch.arange(n, dtype=torch.float64)[None, :])
+                assert torch.equal(E_all.cpu(), want), "gathered stand-in spectra are not in channel order"
+
+        def describe(rec):
+            per = "/".join(str(c) for c in sorted(set(rec["counts"]), reverse=True))
+            return ("%d l-channels per GPU, %d in total" % (args.channels, rec["total"])) if rec["mode"] == "weak" else \
+                   ("%d l-channels in total, %s per GPU" % (rec["total"], per))
+        out["config"] = {
+            "workload": "Hydrogen Coulomb l=%d..%d, N_bsp=%d, k=%d, KIND_GRID=0 rb=%g (BASELINE configs[3]); `value` = %s scaling: %s"
+                        % (0, total - 1, n, args.k, args.rb, args.scaling, describe(main)),
+            "channels_per_gpu": counts, "channels_total": total, "eigenvector_owner_rank": main["owner"],
+            "parallelism": "l-sharded x%d (bspatom_amd/parallel.py), %s all-gather of spectra"
+                           % (world, ("gloo (launcher self-test, no solve)" if selftest else "RCCL") if use_dist else "no (single process)"),
+            "collective_calls": parallel.COLLECTIVE_CALLS, "launched_by": "torch.distributed.run" if use_dist else "python"}
+        if selftest:
+            out["data"] = "launcher self-test: stand-in spectra, no solve"
+        for rec in recs[1:]:
+            key = "configs3_as_stated" if rec["mode"] == "strong" else "weak_scaling"
+            out[key] = {"scaling": rec["mode"], "value": rec["value"], "unit": "eigensolves/s", "ms_per_step": rec["ms_per_step"],
+                        "steps": args.steps, "warmup": args.warmup, "workload": describe(rec),
+                        "channels_per_gpu": rec["counts"], "channels_total": rec["total"],
+                        "stage_ms_per_step_rank0": dict(zip(["assemble", "chol_std", "sy2sb", "sb2st", "bisect", "total_device"],
+                                                            [float(x) for x in rec["stage_ms"]]))}
+        if not selftest:
+            out.update(report(args, world, n, prob.npad, main, ktimes, kstage))
+            if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (rank 0's host cores)
+                out["cpu_baseline"] = cpu_baseline(args.cpu_sample_nfun, args.k)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if prob is not None:
+        prob.close()
+
+
+def report(args, world, n, npad, main, ktimes, kstage):
+    """roofline (whole path + per kernel), stage times and the Rydberg check of rank 0's spectra."""
+    import numpy as np
+    from bspatom_amd import capi
+    total, nl = main["total"], main["nl"]
+    E_all = main["E_all"]
+    Eh = E_all[0].cpu().numpy()
+    ryd = max(abs(Eh[i] + 0.5 / (i + 1) ** 2) / (0.5 / (i + 1) ** 2) for i in range(8))
+    Elast = E_all[total - 1].cpu().numpy()                      # a channel the last rank solved
+    assert np.all(np.diff(Elast) >= 0) and (total == 1 or Elast[0] > Eh[0])
+    stage_ms = main["stage_ms"]
+    b = 64
+    F = 4.0 / 3.0 * n ** 3 + 4.0 * n ** 2 * args.k            # SURVEY 8(d) flops per l-channel
+    names = ["assemble", "chol_std", "sy2sb", "sb2st", "bisect"]
+    pmc, pmc_file, pmc_stale, mfma, mfma_file, mfma_stale = profile_summary(nl, n)
+
+    def pmc_bytes(kname):
+        if not pmc:
+            return None
+        for k, v in pmc.get("kernels", {}).items():
+            if kname in k:
+                return v["traffic_bytes_per_launch"]
+        return None
+
+    def kt(sub):
+        hit = [(k, v) for k, v in (ktimes or {}).items() if sub in k]
+        return hit[0][1] if hit else (0.0, 0)
+
+    kern = []
+    src_live = "HIP events around every launch, one extra untimed step of this run (bspatom_kernel_times)"
+    # ---- sy2sb: the two big products against the MFMA peak.  Launches of the two channel groups overlap, so a kernel's summed
+    # launch durations exceed the wall time it occupies; its SHARE of the stage's wall time is taken as
+    # stage wall (HIP events, this run) x its summed durations / the summed durations of all sy2sb kernels.
+    sy_ms = float(kstage["sy2sb"]) if kstage else float(stage_ms[2])
+    sy_slots = ["syr2k", "symm", "panel_qr", "sy2sb chain"]
+    sy_sum = sum(kt(s)[0] for s in sy_slots)
+    for sub, flop, label, prof in (("syr2k", syr2k_tiles(npad) * 2.0 * 128 ** 3 * nl, "rank-128 update A22 -= [V Z][Z V]^T (syr2k)", "gemm2_kernel<128, 128"),
+                                   ("symm", symm_tiles(npad) * 2.0 * 64 * 128 * nl, "symm Y = A22 W", "gemm2_kernel<64, 128")):
+        ms_sum, calls = kt(sub)
+        if calls == 0:
             continue
-        if d.get("workload", {}).get("channels") == channels and d.get("workload", {}).get("nfun") == nfun:
-            pmc, pmc_file = d, os.path.relpath(f, ROOT)
-            break
-    stats, stats_file = {}, None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*final_kernel_stats.csv")), reverse=True):
-        try:
-            for r in csv.DictReader(open(f)):
-                stats[r["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("bsp::", "")] = (float(r["AverageNs"]) * 1e-6, int(r["Calls"]))
-            stats_file = os.path.relpath(f, ROOT)
-            break
-        except Exception:
-            continue
-    mfma, mfma_file = {}, None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mfma_util.json")), reverse=True):
-        try:
-            mfma = {k.replace("bsp::", ""): v for k, v in json.load(open(f))["kernels"].items()}
-            mfma_file = os.path.relpath(f, ROOT)
-            break
-        except Exception:
-            continue
-    return pmc, pmc_file, stats, stats_file, mfma, mfma_file
+        share_ms = sy_ms * ms_sum / sy_sum if sy_sum > 0 else None
+        ach = flop / (share_ms * 1e-3) / 1e12 if share_ms else None
+        util = next((v["mfma_util"] for k, v in mfma.items() if k.startswith(prof)), None)
+        kern.append({"kernel": next(k for k in ktimes if sub in k), "what": label, "bound": "mfma", "launches_per_step": calls,
+                     "avg_launch_ms": ms_sum / calls, "kernel_ms_per_step": ms_sum, "launch_ms_source": src_live,
+                     "share_of_stage_wall_ms": share_ms, "flop_per_step": flop, "achieved": ach, "peak": FP64_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS if ach else None,
+                     "frac_definition": "executed flop / (sy2sb wall time x this kernel's share of the summed launch durations of the stage)",
+                     "tflops_from_overlapped_launch_sums": flop / (ms_sum * 1e-3) / 1e12,
+                     "mfma_pipe_busy": util, "mfma_pipe_busy_source": mfma_file, "mfma_pipe_busy_stale": mfma_stale,
+                     "traffic": pmc_bytes(prof), "traffic_source": pmc_file, "traffic_stale": pmc_stale})
+    qr_ms, qr_calls = kt("panel_qr")
+    ch_ms, ch_calls = kt("sy2sb chain")
+    # ---- bulge chasing against HBM
+    sb_ms = float(stage_ms[3])
+    sb_min = (2.0 * b * n * 8 + 16.0 * n) * nl      # the band read once + d, e written: the data the stage must touch
+    ver = capi.get_option("sb2st_version")
+    two_step = ver == 9 or (ver == 0 and n >= 512)
+    if two_step:
+        # Step 1, sb2sb_mfma_kernel: one launch per wavefront of independent chase items; an item reads and writes a 64 x 64 bulge
+        # tile, the lower triangle of a 64 x 64 diagonal tile and the next 64 x 64 tile.  Step 2, sb16st_kernel: ONE launch; every
+        # pass of 8 sweeps streams the remaining band (32 rows of 8 B per column) through an LDS window once: read + write.
+        items = sum(max(0, -(-(n - 16 * (s_ + 1)) // 64)) for s_ in range((n - 1) // 16))
+        b1 = items * (2 * 64 * 64 * 8 + 2 * 2080 * 8 + 2 * 64 * 64 * 8) * nl
+        b2 = sum(2 * 32 * 8 * (n - s0_) for s0_ in range(0, n - 2, 8)) * nl
+        for sub, bytes_model, note in (("sb2sb_mfma", b1, "item latency at two workgroups per CU"),
+                                       ("sb16st", b2, "serial chase: VALU issue of one 16 x 16 item per wave and step")):
+            ms_sum, calls = kt(sub)
+            if calls == 0:
+                continue
+            name = next(k for k in ktimes if sub in k)
+            tb = pmc_bytes(sub)
+            kern.append({"kernel": name, "bound": "hbm", "launches_per_step": calls, "avg_launch_ms": ms_sum / calls,
+                         "kernel_ms_per_step": ms_sum, "launch_ms_source": src_live, "bytes_model_per_step": bytes_model,
+                         "achieved": bytes_model / (ms_sum * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": bytes_model / (ms_sum * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": tb, "traffic_source": pmc_file, "traffic_stale": pmc_stale, "limited_by": note})
+        kern.append({"kernel": "bulge chasing stage (sb2sb_mfma_kernel + sb16st_kernel)", "bound": "hbm", "launch_ms": sb_ms,
+                     "launch_ms_source": "HIP events around the stage, timed steps of this run", "bytes_min": sb_min,
+                     "bytes_model": b1 + b2, "chase_items_sb2sb_per_channel": items,
+                     "achieved": (b1 + b2) / (sb_ms * 1e-3) / 1e9 if sb_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (b1 + b2) / (sb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sb_ms > 0 else None})
+    else:
+        sb_model = 6.0 * n * n * b * nl
+        kern.append({"kernel": "sb2st_kernel_v7<0>", "bound": "hbm", "launch_ms": sb_ms, "launch_ms_source": "HIP events, this run",
+                     "bytes_min": sb_min, "bytes_pass_model": sb_model,
+                     "achieved": sb_model / (sb_ms * 1e-3) / 1e9 if sb_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": sb_model / (sb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sb_ms > 0 else None,
+                     "traffic": pmc_bytes("sb2st_kernel_v7"), "traffic_source": pmc_file, "traffic_stale": pmc_stale})
+    other = {"panel_qr": {"kernel_ms_per_step": qr_ms, "launches_per_step": qr_calls},
+             "sy2sb_chain_small_products": {"kernel_ms_per_step": ch_ms, "launches_per_step": ch_calls},
+             "bisect3_kernel": dict(zip(("kernel_ms_per_step", "launches_per_step"), kt("bisect3"))),
+             "cholesky_std_form": dict(zip(("kernel_ms_per_step", "launches_per_step"), kt("std_form")))}
+    # the path as a whole, SURVEY 8(d): F(n) flop per l-channel against the fp64 peak of the GPUs used
+    ach = F * main["value"] / 1e12
+    roof = {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+            "frac": ach / (FP64_PEAK_TFLOPS * world),
+            "scope": "whole path: F(n) = 4/3 n^3 + 4 n^2 k flop per l-channel (SURVEY 8d) x eigensolves/s, against the fp64 "
+                     "matrix/vector peak of %d GPU(s)" % world,
+            "traffic": (sum(v["traffic_bytes_per_launch"] * v["launches"] for v in pmc["kernels"].values()) if pmc else None),
+            "traffic_note": "HBM bytes of ONE STEP (all kernels: sum of launches x bytes per launch), from the committed profile "
+                            "%s%s -- not measured in this run" % (pmc_file, " (STALE: taken with other kernel sources)" if pmc_stale else ""),
+            "kernels": kern, "other_kernels_this_run": other,
+            "kernel_timing_step_stage_ms": kstage}
+    return {"roofline": roof,
+            "stage_ms_per_step_rank0": dict(zip(names + ["total_device"], [float(x) for x in stage_ms])),
+            "rydberg_max_rel_err_n<=8": ryd, "csrc_sha16": kernel_sources_sha()}
 
 
 def main():
@@ -119,221 +451,18 @@ def main():
     ap.add_argument("--k", type=int, default=9)
     ap.add_argument("--rb", type=float, default=800.0)
     ap.add_argument("--channels", type=int, default=128,
-                    help="l-channels per GPU (--scaling weak) or in total (--scaling strong)")
+                    help="l-channels per GPU (weak) and in total (strong: BASELINE configs[3] as stated)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: every GPU solves --channels channels (BASELINE configs[3] at N=1); strong: configs[3] as "
-                         "stated, --channels = 128 in total, 128/N per GPU")
+                    help="which sharding is `value`: weak = every GPU solves --channels channels (BASELINE configs[3] at N=1); strong = "
+                         "--channels in total, --channels/N per GPU.  At N > 1 the other one is measured too and reported beside it")
     ap.add_argument("--cpu-sample-nfun", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU rehearsal of the N-rank launch path (gloo, stand-in spectra, no GPU, no solve): tests only")
     args = ap.parse_args()
-
-    import torch                      # first: its HIP runtime is the one the process uses
-    import torch.distributed as dist
-    import numpy as np
-    from bspatom_amd import capi, parallel
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            sys.stderr.write("bench: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE\n" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: libbspatom has no CPU path")
-    torch.cuda.set_device(local)
-    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # launched by torch.distributed.run (also at N=1)
-    # rank 0 prints ONE line on stdout: RCCL writes its banner (version, hostname, library path) to stdout when the
-    # communicator is created, so everything but the result line goes to stderr
-    real_stdout = os.dup(1)
-    sys.stdout.flush()
-    os.dup2(2, 1)
-    if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-
-    # l-sharding (bspatom_amd/parallel.py -- the code the gloo world-size-2 tests cover)
-    if args.scaling == "weak":
-        total = world * args.channels
-        counts = [parallel.channel_range(r, world, total - 1, per_rank=args.channels)[1] for r in range(world)]
-        l0, nl = parallel.channel_range(rank, world, total - 1, per_rank=args.channels)
-    else:
-        total = args.channels
-        counts = [parallel.channel_range(r, world, total - 1)[1] for r in range(world)]
-        l0, nl = parallel.channel_range(rank, world, total - 1)
-    l_ini = 0
-    owner = next(r for r in range(world) if sum(counts[:r]) <= l_ini < sum(counts[:r + 1]))
-    inp = capi.make_input(kind_grid=0, ra=0.0, rb=args.rb, k=args.k, nfun=args.nfun, n0_ini=1, l_ini=l_ini,
-                          l_fin=total - 1, zatom=1.0)
-    prob = capi.Problem(inp, device=local)
-    n = prob.nfun
-    E_dev = torch.empty(max(nl, 1) * n, dtype=torch.float64, device="cuda")
-    E_all = None
-
-    stage_ms = np.zeros(6)
-
-    def step(timed):
-        nonlocal E_all
-        if nl > 0:
-            info = prob.solve_dev(l0, nl, E_dev.data_ptr())      # returns when the library's stream has drained
-            assert (info == 0).all()
-            if timed:
-                t = prob.last_timing()
-                stage_ms[:] += [t["assemble"], t["chol_std"], t["sy2sb"], t["sb2st"], t["bisect"], t["total"]]
-        if rank == owner:             # owner of l_ini: the one eigenvector KIND_PI=0 consumes + WRITE_WF
-            c = prob.eigvec(l_ini, 1)
-            prob.write_wf(c)
-        # RCCL all-gather of the spectra: the only collective of the path.  E_dev is rewritten by the next solve on the
-        # library's own stream, so the gather must have completed before the step ends.
-        E_all = parallel.gather_spectra(E_dev[: nl * n], n, counts)
-        if use_dist:
-            torch.cuda.current_stream().synchronize()
-
-    def sync():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step(False)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    sync()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    if rank == 0:
-        assert tuple(E_all.shape) == (total, n)
-        Eh = E_all[0].cpu().numpy()
-        ryd = max(abs(Eh[i] + 0.5 / (i + 1) ** 2) / (0.5 / (i + 1) ** 2) for i in range(8))
-        Elast = E_all[total - 1].cpu().numpy()                      # a channel the last rank solved
-        assert np.all(np.diff(Elast) >= 0) and Elast[0] > Eh[0]
-        stage_ms /= max(args.steps, 1)
-        units = total * args.steps
-        value = units / dt
-        b = 64
-        F = 4.0 / 3.0 * n ** 3 + 4.0 * n ** 2 * args.k            # SURVEY 8(d) flops per l-channel
-        names = ["assemble", "chol_std", "sy2sb", "sb2st", "bisect"]
-        pmc, pmc_file, kstats, stats_file, mfma, mfma_file = profile_summary(nl, n)
-
-        def pmc_bytes(kname):
-            if not pmc:
-                return None
-            for k, v in pmc.get("kernels", {}).items():
-                if kname in k:
-                    return v["traffic_bytes_per_launch"]
-            return None
-
-        # per-kernel rooflines.  sb2st is ONE launch per step: its duration is this run's HIP-event time on the
-        # library's stream.  The two big GEMM kernels of sy2sb are ~190 launches each, overlapped on several streams:
-        # their durations are the kernel-trace averages of the committed profile of this same command.
-        kern = []
-        sb_ms = float(stage_ms[3])
-        # bulge chasing, n^2/(2b) chase items per channel, each with one b x b block and one b x b symmetric block.
-        # bytes_min: the band read once + d, e written (what SURVEY 8(d) calls algorithmic: the data the stage must
-        # touch); bytes_pass_model: what the two-sweeps-per-pass scheme moves by construction (an item's tiles read by
-        # the first sweep of a pair, written by the second: 6 n^2 b B per channel).
-        sb_min = (2.0 * b * n * 8 + 16.0 * n) * nl
-        ver = capi.get_option("sb2st_version")
-        two_step = ver == 9 or (ver == 0 and n >= 512)
-
-        def from_stats(sub):
-            hit = [(k, v) for k, v in kstats.items() if sub in k]
-            if not hit:
-                return None
-            calls = sum(v[1] for _, v in hit)
-            return {"launches_per_step": calls / 5.0, "avg_launch_ms": sum(v[0] * v[1] for _, v in hit) / calls,
-                    "kernel_ms_per_step": sum(v[0] * v[1] for _, v in hit) / 5.0, "source": stats_file,
-                    "traffic_bytes_per_launch": pmc_bytes(sub), "traffic_source": pmc_file}
-
-        if two_step:
-            # Two steps (csrc/sbr2.hip).  Step 1, sb2sb_mfma_kernel: one launch per wavefront of independent chase items (sweep of
-            # 16 columns s, step k, t = k + 3 s); an item reads and writes a 64 x 64 bulge tile, the lower triangle of a 64 x 64
-            # diagonal tile and the next 64 x 64 tile.  Step 2, sb16st_kernel: ONE launch; every pass of 8 sweeps streams the
-            # remaining band (32 rows of 8 B per column) through an LDS window once: read + write.
-            items = sum(max(0, -(-(n - 16 * (s_ + 1)) // 64)) for s_ in range((n - 1) // 16))
-            b1 = items * (2 * 64 * 64 * 8 + 2 * 2080 * 8 + 2 * 64 * 64 * 8) * nl
-            b2 = sum(2 * 32 * 8 * (n - s0_) for s0_ in range(0, n - 2, 8)) * nl
-            kern.append({"kernel": "sb2sb_mfma_kernel (band 64 -> 16, one launch per wavefront) + sb16st_kernel (band 16 -> 1, one launch)",
-                         "bound": "hbm", "launch_ms": sb_ms, "launch_ms_source": "HIP events around the stage, this run",
-                         "bytes_min": sb_min, "bytes_model": b1 + b2, "bytes_model_sb2sb": b1, "bytes_model_sb16st": b2,
-                         "chase_items_sb2sb_per_channel": items,
-                         "achieved": (b1 + b2) / (sb_ms * 1e-3) / 1e9 if sb_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (b1 + b2) / (sb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sb_ms > 0 else None,
-                         "split_from_profile": {"sb2sb_mfma_kernel": from_stats("sb2sb_mfma_kernel"),
-                                                "sb16st_kernel": from_stats("sb16st_kernel")},
-                         "traffic": (sum(v["traffic_bytes_per_launch"] * v["launches"] for k_, v in pmc["kernels"].items()
-                                         if "sb2sb_mfma_kernel" in k_ or "sb16st_kernel" in k_) or None) if pmc else None,
-                         "traffic_source": pmc_file,
-                         "note": "step 2 is bound by the serial chase (one 16 x 16 item per wave and step, ~1.8 us per step), "
-                                 "not by memory; step 1 by item latency at two workgroups per CU"})
-        else:
-            sb_model = 6.0 * n * n * b * nl
-            kern.append({"kernel": "sb2st_kernel_v7<0>", "bound": "hbm", "launch_ms": sb_ms, "launch_ms_source": "HIP events, this run",
-                         "bytes_min": sb_min, "bytes_pass_model": sb_model,
-                         "achieved": sb_model / (sb_ms * 1e-3) / 1e9 if sb_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": sb_model / (sb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sb_ms > 0 else None,
-                         "frac_of_min_bytes": sb_min / (sb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sb_ms > 0 else None,
-                         "traffic": pmc_bytes("sb2st_kernel_v7"), "traffic_source": pmc_file})
-        # rank-128 update executes 0.55 of 2 n^3 / 3 ... per channel: sum over panels of the valid tiles; symm 2 n^3 / 3
-        for kname, flop, label in (("gemm2_kernel<128, 128", 0.55 * 4.0 / 3.0 * n ** 3 * nl, "rank-128 update (syr2k)"),
-                                   ("gemm2_kernel<64, 128", 2.0 / 3.0 * n ** 3 * nl, "symm Y = A22 W")):
-            hit = [(k, v) for k, v in kstats.items() if k.startswith(kname)]
-            if not hit:
-                continue
-            tot_ms = sum(v[0] * v[1] for _, v in hit)            # all launches of all steps of the profiled run
-            calls = sum(v[1] for _, v in hit)
-            steps_prof = 5.0                                      # tools/gpu_profiles.sh: --steps 4 --warmup 1
-            per_step_ms = tot_ms / steps_prof
-            # achieved: the MFMA pipe's busy share of the kernel running ALONE (counter pass, profiles/*_mfma_util.json:
-            # SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles) x peak; in the pipeline the launches of two channel groups overlap,
-            # so the sum of their durations (kernel_ms_per_step) exceeds the wall time they occupy
-            util = next((v["mfma_util"] for k, v in mfma.items() if k.startswith(kname)), None)
-            ach = util * FP64_PEAK_TFLOPS if util is not None else flop / (per_step_ms * 1e-3) / 1e12
-            kern.append({"kernel": kname + ", ...>", "what": label, "bound": "mfma", "launches_per_step": calls / steps_prof,
-                         "kernel_ms_per_step": per_step_ms, "launch_ms_source": stats_file,
-                         "flop_per_step": flop, "achieved": ach, "peak": FP64_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
-                         "achieved_source": (mfma_file + " (MFMA pipe busy, kernel alone)") if util is not None else "flop / sum of overlapped launch durations",
-                         "tflops_from_overlapped_launch_sums": flop / (per_step_ms * 1e-3) / 1e12,
-                         "traffic": pmc_bytes(kname), "traffic_source": pmc_file})
-        # the path as a whole, SURVEY 8(d): F(n) flop per l-channel against the fp64 peak of the GPUs used
-        ach = F * value / 1e12
-        roof = {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS * world, "unit": "TFLOP/s",
-                "frac": ach / (FP64_PEAK_TFLOPS * world),
-                "scope": "whole path: F(n) = 4/3 n^3 + 4 n^2 k flop per l-channel (SURVEY 8d) x eigensolves/s, against the fp64 "
-                         "matrix/vector peak of %d GPU(s)" % world,
-                "traffic": (sum(v["traffic_bytes_per_launch"] * v["launches"] for v in pmc["kernels"].values()) if pmc else None),
-                "traffic_note": "HBM bytes of ONE STEP (all kernels: sum of launches x bytes per launch), from the committed profile "
-                                "%s -- not measured in this run" % pmc_file,
-                "kernels": kern}
-        out = {
-            "metric": "l-channel eigensolves/sec at N_bsp=%d fp64" % n, "value": value, "unit": "eigensolves/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Hydrogen Coulomb l=%d..%d, N_bsp=%d, k=%d, KIND_GRID=0 rb=%g (BASELINE configs[3]); "
-                                   "%s" % (0, total - 1, n, args.k, args.rb,
-                                           ("%d l-channels per GPU" % args.channels) if args.scaling == "weak" else
-                                           ("%d l-channels in total, %s per GPU" % (total, "/".join(str(c) for c in sorted(set(counts)))))),
-                       "channels_per_gpu": counts, "channels_total": total, "eigenvector_owner_rank": owner,
-                       "parallelism": "l-sharded x%d (bspatom_amd/parallel.py), %s all-gather of spectra"
-                                      % (world, "RCCL" if use_dist else "no (single process)")},
-            "roofline": roof,
-            "stage_ms_per_step_rank0": dict(zip(names + ["total_device"], [float(x) for x in stage_ms])),
-            "rydberg_max_rel_err_n<=8": ryd,
-        }
-        if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (rank 0's host cores)
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_nfun, args.k)
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
-    prob.close()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+    run(args)
 
 
 if __name__ == "__main__":

@@ -35,7 +35,7 @@ EXPORTS = ["bspatom_input_defaults", "bspatom_device_count", "bspatom_host_setup
            "bspatom_problem_sizes", "bspatom_problem_grid", "bspatom_assemble", "bspatom_solve", "bspatom_solve_dev",
            "bspatom_eigvec", "bspatom_eigvecs", "bspatom_dipole_bands", "bspatom_dipole_elements", "bspatom_write_wf", "bspatom_last_timing", "bsp_dsygv_", "bspatom_stage_gemm",
            "bspatom_stage_standard_form", "bspatom_stage_sy2sb", "bspatom_stage_sb2st", "bspatom_stage_sb2sb", "bspatom_stage_bisect",
-           "bspatom_set_option", "bspatom_get_option"]
+           "bspatom_set_option", "bspatom_get_option", "bspatom_kernel_times", "bspatom_kernel_slot_name"]
 
 _lib = None
 
@@ -75,6 +75,9 @@ def lib():
         L.bsp_dsygv_.restype = None
         L.bspatom_set_option.argtypes = [C.c_char_p, i32]
         L.bspatom_get_option.argtypes = [C.c_char_p, C.POINTER(i32)]
+        L.bspatom_kernel_times.argtypes = [vp, vp, i32]
+        L.bspatom_kernel_slot_name.argtypes = [i32]
+        L.bspatom_kernel_slot_name.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -277,6 +280,15 @@ def dsygv(A, B, jobz="V", uplo="U"):
 def set_option(name, value):
     """Flip one of the library's run-time switches (BSP_* variables of DESIGN.md 4.4) in this process."""
     _chk(lib().bspatom_set_option(name.encode(), int(value)), "bspatom_set_option(%s)" % name)
+
+
+def kernel_times():
+    """Launch durations recorded since the last call while option "ktime" was 1: {slot name: (sum of ms, launches)}."""
+    ms = np.zeros(16); cnt = np.zeros(16, dtype=np.int32)
+    ns = lib().bspatom_kernel_times(_p(ms), _p(cnt), 16)
+    if ns < 0:
+        raise BspAtomError(ns, "bspatom_kernel_times")
+    return {lib().bspatom_kernel_slot_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(ns)}
 
 
 def get_option(name):

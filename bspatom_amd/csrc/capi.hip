@@ -1,6 +1,7 @@
 // capi.hip -- the C ABI of libbspatom (include/bspatom.h): problem handle, the batched solve
 // pipeline and the stage-level entry points.  One HIP stream per problem; every stage of a solve
 // is enqueued on it back-to-back (no host synchronisation between stages) and timed with events.
+#include <atomic>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -43,6 +44,21 @@ struct bspatom_problem {
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+namespace bsp {
+static std::atomic<int> g_process_device{-1};
+int process_device() { return g_process_device.load(); }
+int process_device_check(int device)
+{
+    const int cur = g_process_device.load();
+    if (cur >= 0 && cur != device) {
+        fprintf(stderr, "bspatom: this process already works on device %d; use one process per GPU (device %d refused)\n", cur, device);
+        return BSP_ERR_UNSUPPORTED;
+    }
+    return BSP_OK;
+}
+void process_device_latch(int device) { int expect = -1; g_process_device.compare_exchange_strong(expect, device); }
+}  // namespace bsp
+
 // ---- run-time switches: environment once, then bspatom_set_option ------------------------------------
 namespace {
 struct OptName { const char *name; const char *env; int Options::*field; };
@@ -57,6 +73,7 @@ const OptName OPT_TABLE[] = {
     {"bisect_ept", "BSP_BISECT_EPT", &Options::bisect_ept},
     {"bisect_tail", "BSP_BISECT_TAIL", &Options::bisect_tail}, {"no_eigvec_prefetch", "BSP_NO_EIGVEC_PREFETCH", &Options::no_eigvec_prefetch},
     {"poison_c", "BSP_POISON_C", &Options::poison_c}, {"sb2sb_mfma", "BSP_SB2SB_MFMA", &Options::sb2sb_mfma},
+    {"ktime", "BSP_KTIME", &Options::ktime},
 };
 }  // namespace
 
@@ -73,7 +90,59 @@ Options &opts()
     }();
     return o;
 }
+
+// ---- per-kernel launch timing (common.h: KSlot) -------------------------------------------------------
+namespace {
+struct KRec { int slot; hipEvent_t e0, e1; };
+std::vector<KRec> g_krecs;                  // launches recorded since the last collection (one host thread per problem)
+std::vector<hipEvent_t> g_kpool;            // events ready for reuse
+hipEvent_t g_kopen[KS_COUNT];               // start event of the launch being recorded, per slot
+hipEvent_t kevent()
+{
+    hipEvent_t e = nullptr;
+    if (!g_kpool.empty()) { e = g_kpool.back(); g_kpool.pop_back(); }
+    else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+    return e;
+}
+const char *const KSLOT_NAMES[KS_COUNT] = {"gemm2_kernel<128,128,MODE 1> (rank-128 update, syr2k)", "gemm2_kernel<64,128,MODE 2> (symm Y = A22 W)",
+                                          "panel_qr2_kernel / panel_qr_kernel", "sy2sb chain: G, K (split-K gemm_kernel + splitk_reduce), form_T, tsmm64 (W, Z)",
+                                          "sb2sb_mfma_kernel (band 64 -> 16)", "sb16st_kernel (band 16 -> 1)", "bisect3_kernel",
+                                          "band_cholesky_kernel + std_form_kernel"};
+}  // namespace
+void ktime_begin(int slot, hipStream_t st)
+{
+    hipEvent_t e = kevent();
+    g_kopen[slot] = e;
+    if (e) (void)hipEventRecord(e, st);
+}
+void ktime_end(int slot, hipStream_t st)
+{
+    hipEvent_t e0 = g_kopen[slot], e1 = kevent();
+    g_kopen[slot] = nullptr;
+    if (!e0 || !e1) return;
+    (void)hipEventRecord(e1, st);
+    g_krecs.push_back({slot, e0, e1});
+}
 }  // namespace bsp
+
+extern "C" int bspatom_kernel_times(double *ms, int32_t *launches, int cap)
+{
+    if (!ms || !launches || cap < KS_COUNT) return BSP_ERR_ARG;
+    BSP_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < cap; ++i) { ms[i] = 0.0; launches[i] = 0; }
+    for (const auto &r : g_krecs) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) { ms[r.slot] += t; launches[r.slot] += 1; }
+        g_kpool.push_back(r.e0); g_kpool.push_back(r.e1);
+    }
+    g_krecs.clear();
+    return KS_COUNT;
+}
+
+extern "C" const char *bspatom_kernel_slot_name(int slot)
+{
+    return (slot >= 0 && slot < KS_COUNT) ? KSLOT_NAMES[slot] : nullptr;
+}
 
 extern "C" int bspatom_set_option(const char *name, int value)
 {
@@ -193,18 +262,16 @@ extern "C" int bspatom_problem_create(const bspatom_input *in, int device, bspat
     }
     // One process per GPU: the kernels' opt-ins for large LDS, the side streams of sy2sb and the stage-level
     // scratch buffers are created once per process on the device of the first problem.
-    static int first_device = -1;
-    if (first_device < 0) first_device = device;
-    if (device != first_device) {
-        fprintf(stderr, "bspatom: this process already works on device %d; use one process per GPU (device %d refused)\n",
-                first_device, device);
-        return BSP_ERR_UNSUPPORTED;
-    }
+    // The device is latched by the first problem that was created SUCCESSFULLY and stays latched for the life of the process
+    // (those per-process objects live on it); bsp_dsygv_ (dsygv.hip) honours the same latch.
+    int rc0;
+    if ((rc0 = bsp::process_device_check(device))) return rc0;
     bspatom_problem *p = new (std::nothrow) bspatom_problem;
     if (!p) return BSP_ERR_ARG;
     p->device = device;
     const int rc = problem_init(p, in, device);
     if (rc) { bspatom_problem_destroy(p); return rc; }      // frees whatever was created so far
+    bsp::process_device_latch(device);
     *out = p;
     return BSP_OK;
 }
@@ -320,9 +387,12 @@ int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const d
                      double *d_Eout, hipStream_t st, hipEvent_t *ev, bool with_bisect)
 {
     int rc;
-    if ((rc = launch_band_cholesky(n, k, d_SB, b.UB, b.rdiag, b.info, st))) return rc;
     if (opts().poison_c) BSP_HIP(hipMemsetAsync(b.C, 0xFF, (size_t)nl * npad * npad * sizeof(double), st));
-    if ((rc = launch_standard_form(n, npad, k, nl, d_HB, b.UB, b.rdiag, b.Y, b.C, st))) return rc;
+    {
+        KScope kt(KS_STDFORM, st);
+        if ((rc = launch_band_cholesky(n, k, d_SB, b.UB, b.rdiag, b.info, st))) return rc;
+        if ((rc = launch_standard_form(n, npad, k, nl, d_HB, b.UB, b.rdiag, b.Y, b.C, st))) return rc;
+    }
     if (ev) BSP_HIP(hipEventRecord(ev[1], st));
     Sy2sbWork w;
     sy2sb_carve(b.work, npad, 64, nl, &w);

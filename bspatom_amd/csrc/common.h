@@ -53,8 +53,28 @@ struct Options {
     int sb2sb_mfma = 1;          // 1: block-chasing item on the matrix cores (sbr2.hip); 0: the first, all-VALU kernel (cross-check)
     int poison_c = 0;            // test hook: fill the dense C buffer with NaN bit patterns before every solve (nothing outside the
                                  // blocks the standard form writes may ever be read)
+    int ktime = 0;               // 1: HIP events around every launch of the kernels in KSlot (bspatom_kernel_times; bench.py's
+                                 // per-kernel roofline entries are measured with it in one extra, untimed step)
 };
 Options &opts();
+
+// one process per GPU: the device of the first successfully created problem (capi.hip); -1 while none exists
+int process_device();
+int process_device_check(int device);          // BSP_OK, or BSP_ERR_UNSUPPORTED (message on stderr) if another device is latched
+void process_device_latch(int device);
+
+// ---- per-kernel launch timing (off unless opts().ktime) --------------------------------------------
+// Two events per launch, recorded on the launch's own stream; bspatom_kernel_times() sums the elapsed times per slot after
+// the device has drained.  Launches of different streams overlap, so the sums of a slot are sums of launch DURATIONS (what
+// rocprofv3 --kernel-trace --stats reports), not wall time.
+enum KSlot { KS_SYR2K = 0, KS_SYMM, KS_PANEL_QR, KS_CHAIN, KS_SB2SB, KS_SB16ST, KS_BISECT, KS_STDFORM, KS_COUNT };
+void ktime_begin(int slot, hipStream_t st);
+void ktime_end(int slot, hipStream_t st);
+struct KScope {
+    int slot; hipStream_t st; bool on;
+    KScope(int slot_, hipStream_t st_) : slot(slot_), st(st_), on(opts().ktime != 0) { if (on) ktime_begin(slot, st); }
+    ~KScope() { if (on) ktime_end(slot, st); }
+};
 
 // ---- batched fp64 MFMA GEMM: C[b] = alpha * A[b] * B[b] + beta * C[b] ----------------------
 // Element (i,k) of A[b] is at A + b*bA + i*sAm + k*sAk (one of sAm, sAk must be 1), likewise

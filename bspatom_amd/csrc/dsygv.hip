@@ -52,6 +52,14 @@ extern "C" void bsp_dsygv_(const int *itype, const char *jobz, const char *uplo,
         *info = n;
         return;
     }
+    // one process per GPU: the device the process's problems live on (capi.hip), else the caller's current device, which is
+    // then latched like a problem's would be -- the per-process streams and scratch of the pipeline live on it
+    {
+        int dev = process_device();
+        if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+        if (process_device_check(dev) != BSP_OK || hipSetDevice(dev) != hipSuccess) { *info = n; return; }
+        process_device_latch(dev);
+    }
     auto at = [&](const double *m, int ld, int i, int j) -> double {   // element (i,j), i <= j, of the stored triangle
         return upper ? m[(size_t)j * ld + i] : m[(size_t)i * ld + j];
     };

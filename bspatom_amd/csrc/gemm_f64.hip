@@ -666,6 +666,7 @@ int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const doub
     }
     g.lower_only = T;                                                 // MODE 1 reads it as the tile count
     dim3 grid((unsigned)(8 * ((batch + 7) / 8) * T), 1, 1);
+    KScope kt(KS_SYR2K, st);
     const int gd = opts().gemm_diag;
     if (gd && part == 2 && m >= 3900) {
         long long z[8] = {0};
@@ -697,6 +698,7 @@ int symm_lower_f64(int m, int batch, const double *A22, long ld, long bsA, const
     g.C = Y; g.sCm = ldy; g.sCn = 1; g.bC = bsY;                      // C'(c, i) = Y(i, c)
     g.alpha = 1.0; g.beta = 0.0; g.lower_only = 0;
     dim3 grid((unsigned)(8 * ((batch + 7) / 8) * ((m + 127) / 128)), 1, 1);
+    KScope kt(KS_SYMM, st);
     hipLaunchKernelGGL((gemm2_kernel<64, 128, 1, 0, 2>), grid, dim3(256), 0, st, g);
     BSP_HIP(hipGetLastError());
     return BSP_OK;

@@ -608,13 +608,18 @@ constexpr unsigned long long S16_COMMIT = 1ull << 62, S16_ABORT = 1ull << 63;
 
 __device__ __forceinline__ void s16_wait(const unsigned long long *pollp, unsigned long long want, Sb16Ctl *C, int *status)
 {
+    // A wait that timed out once has set C->err: every later wait of the channel gives up after a short spin instead of its
+    // full bound, so that a stalled ring member ends the launch in milliseconds with the status word set, not in minutes
+    // (the channel's results are void either way: BSP_ERR_HIP is returned).
     int spin = 0;
+    const int bound = __hip_atomic_load(&C->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 2000 : 20000000;
     while (__hip_atomic_load(pollp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        if (++spin > 20000000) {                          // never seen; ends the wait instead of the machine
+        if (++spin > bound) {                             // never seen; ends the wait instead of the machine
             atomicExch(&C->err, 1);
             if (status) atomicExch(status, BSP_ERR_HIP);
             break;
         }
+        if ((spin & 1023) == 0 && __hip_atomic_load(&C->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         __builtin_amdgcn_s_sleep(2);
     }
     asm volatile("buffer_inv sc1" ::: "memory");
@@ -814,14 +819,6 @@ int launch_sb2sb(int n, int npad, int batch, double *d_AB, hipStream_t st)
         attr = true;
     }
     const int mf = opts().sb2sb_mfma;
-    static int ldspad = -1;                                 // timing experiment: BSP_SB2SB_LDSPAD=30000 leaves one workgroup per CU
-    if (ldspad < 0) {
-        const char *e = getenv("BSP_SB2SB_LDSPAD");
-        ldspad = e ? atoi(e) : 0;
-        if (ldspad > 0)
-            BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sb2sb_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        SB2SB2_LDS + ldspad));
-    }
     if (opts().sb2st_diag) {
         int nb1 = 0, nb2 = 0;
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, reinterpret_cast<const void *>(sb2sb_mfma_kernel), 256, SB2SB2_LDS);
@@ -840,7 +837,8 @@ int launch_sb2sb(int n, int npad, int batch, double *d_AB, hipStream_t st)
         if (t - LAG * s_hi >= K(s_hi)) continue;
         int s_lo = s_hi;
         while (s_lo > 0 && t - LAG * (s_lo - 1) < K(s_lo - 1)) --s_lo;
-        if (mf) hipLaunchKernelGGL(sb2sb_mfma_kernel, dim3(s_hi - s_lo + 1, batch), dim3(256), SB2SB2_LDS + ldspad, st, n, npad, d_AB, t, s_lo);
+        KScope kt(KS_SB2SB, st);
+        if (mf) hipLaunchKernelGGL(sb2sb_mfma_kernel, dim3(s_hi - s_lo + 1, batch), dim3(256), SB2SB2_LDS, st, n, npad, d_AB, t, s_lo);
         else hipLaunchKernelGGL(sb2sb_kernel, dim3(s_hi - s_lo + 1, batch), dim3(256), SB2SB_LDS, st, n, npad, d_AB, t, s_lo);
     }
     BSP_HIP(hipGetLastError());
@@ -881,17 +879,23 @@ int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double 
     if (opts().sb2st_diag) {                                // cycles per phase of the chasing waves (workgroup 0)
         long long *dbuf = nullptr, h[45];
         BSP_HIP(hipMalloc(reinterpret_cast<void **>(&dbuf), sizeof(h)));
+        BSP_HIP(hipMemsetAsync(dbuf, 0, sizeof(h), st));
         hipLaunchKernelGGL(sb16st_kernel, dim3(nblk), dim3(576), SB16_LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf, d_ctl, P,
                            d_status, fab);
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) { hipFree(dbuf); BSP_HIP(le); }
         BSP_HIP(hipStreamSynchronize(st));
         BSP_HIP(hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost));
         hipFree(dbuf);
-        for (int w = 0; w < 9; ++w)
+        for (int w = 0; w < 9; ++w) {
+            const double steps = h[w * 5 + 4] > 0 ? (double)h[w * 5 + 4] : 1.0;      // workgroup 0 may have left in mode 0: no steps
             fprintf(stderr, "sb16st wave %d: %lld steps; s_memtime ticks per step: chase item %.0f, rest + barrier %.0f (mover wave: columns out %.0f, block in %.0f)\n",
-                    w, h[w * 5 + 4], (double)h[w * 5 + 2] / h[w * 5 + 4], (double)h[w * 5 + 3] / h[w * 5 + 4], (double)h[w * 5] / h[w * 5 + 4],
-                    (double)h[w * 5 + 1] / h[w * 5 + 4]);
+                    w, h[w * 5 + 4], (double)h[w * 5 + 2] / steps, (double)h[w * 5 + 3] / steps, (double)h[w * 5] / steps,
+                    (double)h[w * 5 + 1] / steps);
+        }
         return BSP_OK;
     }
+    KScope kt(KS_SB16ST, st);
     hipLaunchKernelGGL(sb16st_kernel, dim3(nblk), dim3(576), SB16_LDS, st, n, npad, batch, d_AB, d_d, d_e, (long long *)nullptr,
                        d_ctl, P, d_status, fab);
     BSP_HIP(hipGetLastError());

@@ -586,6 +586,7 @@ template <int RPT>
 static void launch_pq(int npad, int r0, int c0, int batch, double *A, double *buf, double *tau, hipStream_t st)
 {
     const int use2 = opts().panel_qr == 2;
+    KScope kt(KS_PANEL_QR, st);
     if (use2 && RPT <= 8) {
         const size_t lds = (size_t)(2 * CW2 * PQ_THREADS * RPT + 128) * sizeof(double);
         static bool attr[17] = {};
@@ -614,6 +615,7 @@ static int panel_and_W(int npad, int c0, int batch, double *d_A, double *buf, do
     else launch_pq<16>(npad, r0, c0, batch, d_A, buf, tau, s);
     BSP_HIP(hipGetLastError());
     int rc;
+    KScope kt(KS_CHAIN, s);
     GemmDesc g{};
     g.batch = batch;
     // G = V^T V
@@ -659,13 +661,16 @@ static int sy2sb_panel(int npad, int batch, double *d_A, const Sy2sbWork &w, hip
         // Y = A22 W  -> buf[:, NB:2NB]   (A22 valid on 64-blocks J <= I+1 only)
         if ((rc = symm_lower_f64(m, batch, A22, ld, bsA, w.W, npad, bsW, buf + (size_t)NB * npad, npad, bsBuf, st))) return rc;
         // K = W^T Y
-        g.M = NB; g.N = NB; g.K = m;
-        g.A = w.W; g.sAm = npad; g.sAk = 1; g.bA = bsW;
-        g.B = buf + (size_t)NB * npad; g.sBk = 1; g.sBn = npad; g.bB = bsBuf;
-        g.C = w.Kmat; g.sCm = 1; g.sCn = NB; g.bC = bsS; g.alpha = 1.0; g.beta = 0.0;
-        if ((rc = gemm_splitk_f64(g, SY2SB_SPLITK, w.part, st))) return rc;
-        // Z = Y - 1/2 V K  (in place; m x 64 times 64 x 64)
-        if ((rc = tsmm64_f64(m, batch, buf, npad, bsBuf, w.Kmat, bsS, buf + (size_t)NB * npad, npad, bsBuf, -0.5, 1.0, st))) return rc;
+        {
+            KScope kt(KS_CHAIN, st);
+            g.M = NB; g.N = NB; g.K = m;
+            g.A = w.W; g.sAm = npad; g.sAk = 1; g.bA = bsW;
+            g.B = buf + (size_t)NB * npad; g.sBk = 1; g.sBn = npad; g.bB = bsBuf;
+            g.C = w.Kmat; g.sCm = 1; g.sCn = NB; g.bC = bsS; g.alpha = 1.0; g.beta = 0.0;
+            if ((rc = gemm_splitk_f64(g, SY2SB_SPLITK, w.part, st))) return rc;
+            // Z = Y - 1/2 V K  (in place; m x 64 times 64 x 64)
+            if ((rc = tsmm64_f64(m, batch, buf, npad, bsBuf, w.Kmat, bsS, buf + (size_t)NB * npad, npad, bsBuf, -0.5, 1.0, st))) return rc;
+        }
         // A22 -= [V Z] [Z V]^T
         const bool more = (p + 1 < P);
         if (lookahead && more) {

@@ -705,6 +705,7 @@ int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_
         attr_set = true;
     }
     const dim3 grid((n + 256 * EPT - 1) / (256 * EPT), batch);
+    KScope kt(KS_BISECT, st);
     if (variant == 1) hipLaunchKernelGGL(bisect_kernel, grid, dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
     else if (variant == 2) hipLaunchKernelGGL(bisect2_kernel, grid, dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
     else {

@@ -113,6 +113,15 @@ int bspatom_write_wf(bspatom_problem *p, const double *c, int npts, double *r, d
  * [3] sb2st, [4] bisection, [5] total.  Also the number of launches of the sy2sb GEMM. */
 int bspatom_last_timing(const bspatom_problem *p, double ms[6]);
 
+/* Per-kernel launch durations (measurement only; no reference counterpart).  With bspatom_set_option("ktime", 1) every launch
+ * of the kernels below is bracketed by two HIP events on its own stream; this call waits for the device, sums the elapsed
+ * times and launch counts per slot since the previous call into ms[] / launches[] (cap >= the slot count, which it returns)
+ * and forgets them.  Slots: 0 rank-128 update (syr2k), 1 symm, 2 panel QR, 3 the small products of the panel chain,
+ * 4 sb2sb_mfma_kernel, 5 sb16st_kernel, 6 batched bisection, 7 Cholesky + standard form; bspatom_kernel_slot_name(i)
+ * names them.  Launches on different streams overlap: the sums are sums of launch durations, not wall time. */
+int bspatom_kernel_times(double *ms, int32_t *launches, int cap);
+const char *bspatom_kernel_slot_name(int slot);
+
 /* ---- LAPACK symbol boundary ---------------------------------------------------- */
 /* Fortran-77 ABI of DSYGV as called at matrices.f90:248.  ITYPE=1, UPLO='U' or 'L'; A and B must
  * be banded with half-width <= 15 (they are, at the reference's call site); JOBZ='N' returns the

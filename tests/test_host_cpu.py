@@ -230,6 +230,62 @@ def test_sharded_host_gloo(tmp_path, case, l_ini):
     assert os.path.isdir(outd / "CSs")
 
 
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_starts_its_own_ranks_gloo(scaling):
+    """`python bench.py --gpus 2` WITHOUT a launcher (the command the driver's N = 1 line generalises to): the parent must
+    start `torch.distributed.run --nproc-per-node 2` as a child, stay off the GPU itself, and relay exactly one JSON line.
+    Rehearsed on the CPU with --selftest-launcher (gloo, stand-in spectra, no solve): sharding, the all-gather, the barrier
+    bracket, the max over ranks and the one-line output are the code the GPU run uses.  At N > 1 the line carries BOTH
+    figures: the weak one (channels per GPU fixed) and configs[3] as stated (channels in total fixed); `value` is the one
+    --scaling names."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nfun", "48",
+                        "--channels", "6", "--scaling", scaling, "--selftest-launcher"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.split("\n") if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout           # stdout is the one line, nothing else
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == scaling and d["value"] > 0
+    assert "no solve" in d["data"]                                           # a self-test line can never pass for a measurement
+    cfg = d["config"]
+    assert cfg["launched_by"] == "torch.distributed.run" and "gloo" in cfg["parallelism"]
+    assert cfg["collective_calls"] == 2 * (2 + 1)                            # both shardings x (steps + warmup)
+    if scaling == "weak":
+        assert cfg["channels_per_gpu"] == [6, 6] and cfg["channels_total"] == 12 and "weak" in cfg["workload"]
+        other = d["configs3_as_stated"]
+        assert other["scaling"] == "strong" and other["channels_per_gpu"] == [3, 3] and other["channels_total"] == 6
+    else:
+        assert cfg["channels_per_gpu"] == [3, 3] and cfg["channels_total"] == 6 and "strong" in cfg["workload"]
+        other = d["weak_scaling"]
+        assert other["scaling"] == "weak" and other["channels_per_gpu"] == [6, 6] and other["channels_total"] == 12
+    assert other["value"] > 0 and other["steps"] == 2
+
+
+def test_bench_refuses_a_world_size_it_was_not_asked_for():
+    """--gpus N under a launcher with WORLD_SIZE != N is an error, not a silent one-rank run labelled n_gpus = N."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launcher"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr and not p.stdout.strip()
+
+
+def test_gather_runs_the_collective_at_world_size_one():
+    """With a process group the all-gather is issued at EVERY world size, 1 included (that is how the RCCL branch is
+    exercised on the one-GPU box, tests/test_a_bench_rccl.py); without one nothing is exchanged."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import torch, torch.distributed as dist\n"
+            "from bspatom_amd import parallel\n"
+            "E = torch.arange(12, dtype=torch.float64)\n"
+            "a = parallel.gather_spectra(E, 4, [3]); assert parallel.COLLECTIVE_CALLS == 0 and a.shape == (3, 4)\n"
+            "dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d', rank=0, world_size=1)\n"
+            "b = parallel.gather_spectra(E, 4, [3]); assert parallel.COLLECTIVE_CALLS == 1 and torch.equal(a, b)\n"
+            "dist.destroy_process_group()\n" % (ROOT, 29300 + os.getpid() % 200))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+
+
 def test_channel_range_partitions():
     from bspatom_amd.parallel import channel_range
     for world in (1, 2, 3, 8):
