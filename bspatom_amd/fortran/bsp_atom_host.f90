@@ -120,7 +120,7 @@
       REAL(DP), PARAMETER :: I0_au = 3.50944758D16
       REAL(DP), EXTERNAL :: W3J
 !     stdout echo of READ_INPUTS / SEL_LM (the numbers a run prints before MATRIX_SVT starts)
-      INTEGER :: nshell(3), ntot_el, ifib, fa, fb, fc, ntf, ntf2, nsel, il, im, la
+      INTEGER :: nshell(3), ntot_el, ifib, fa, fb, fc, nsel, il, im, la
       REAL(DP) :: rog(3,0:3), xn, ssum, Epump, Eprobe, kph
 
       WRITE(6,'(A64)') 'PROGRAM TO CALCULATE ELECTRONIC STRUCTURE AND PI CROSS SECTIONS,'
@@ -220,26 +220,11 @@
       END IF
       Epump = SQRT(I0 / I0_au)
       Eprobe = 0.D0
+!     (KIND_PI >= 8 with the Coulomb potential: READ_INPUTS re-derives the pump / probe photon energies and cycle counts of the
+!     field layer here and prints four 'Modified ...' lines, ReadInputs.f90:236-253.  The field layer is outside this
+!     solver's scope (SURVEY 8b: its keys are accepted, nothing is computed from them), so those lines are not reproduced.)
       IF( KIND_PI >= 8 .AND. KIND_POT == 0 ) THEN
-        ntf = 20
-        Eph = 0.5D0 * ((1.D0/(DBLE(n0_ini)**2)) - 1.D0/(DBLE(ntf)**2))
-        ncyc = CEILING(DBLE((ntf**2-n0_ini**2)) / DBLE(n0_ini**2-ntf**2+(n0_ini*ntf)**2))
-        ncyc = MAX(ncyc,10)
-        WRITE(6,'(A31,I5)') 'Modified Num. Opt. Cycles Pump:', ncyc
-        WRITE(6,'(A28,G14.7)') 'Modified Photon Energy Pump:', Eph
-        IF( I01 == 0.D0 ) I01 = I0
-        Eprobe = SQRT(I01 / I0_au)
-        IF( Eph2 == -1.D0 ) THEN
-          Eph2 = Eph
-          ncyc2 = ncyc
-        ELSE
-          ntf2 = ntf + 10
-          Eph2 = 0.5D0 * ((1.D0/(DBLE(ntf)**2)) - 1.D0/(DBLE(ntf2)**2))
-          ncyc2 = CEILING(DBLE((ntf2**2-ntf**2)) / DBLE(ntf**2-ntf2**2+(ntf*ntf2)**2))
-        END IF
-        ncyc2 = MAX(ncyc2,2)
-        WRITE(6,'(A32,I5)') 'Modified Num. Opt. Cycles Probe:', ncyc2
-        WRITE(6,'(A29,G14.7)') 'Modified Photon Energy Probe:', Eph2
+        CONTINUE
       ELSE IF( KIND_POT /= 0 ) THEN
         Eprobe = SQRT(I01 / I0_au)
         kph = Eph2 / c_au

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 from conftest import load_golden, golden_input, SMALL_CASES, ROOT
 from test_gpu_stages import input_from_case, note
+from tests_truth import truth_stats, ratchet_check
 
 pytestmark = pytest.mark.gpu
 from bspatom_amd import capi
@@ -24,7 +25,7 @@ def load_truth(name):
     return {int(l): (t["idx"][t["chan"] == l], t["hi"][t["chan"] == l]) for l in np.unique(t["chan"])}
 
 
-def full_size_bar(E, Eref, tag, truth=None, judge=None):
+def full_size_bar(E, Eref, tag, truth=None, judge=None, stats=None):
     """Linear-grid parity bar (north_star: every eigenvalue within 1e-10 relative of reference DSYGV).
       (1) normwise |dE| <= 1e-13 lambda_max, every eigenvalue;
       (2) |dE| <= 1e-10 |E_ref| for every eigenvalue, EXCEPT where the reference's own LAPACK value is not determined
@@ -35,8 +36,13 @@ def full_size_bar(E, Eref, tag, truth=None, judge=None):
           reference's does (+1: two LAPACK drivers differ by one on these pencils).
     `judge(indices) -> truth` (optional) computes the 113-bit truth of further eigenvalues on the spot: an exception outside the
     stored set is then adjudicated the same way instead of failing (128 channels at n = 4096: LAPACK's error exceeds 1e-10
-    relative at scattered eigenvalues up to |E| ~ 0.3, too many and too irregular to store them all)."""
+    relative at scattered eigenvalues up to |E| ~ 0.3, too many and too irregular to store them all).
+    `stats` (a list): the channel's GPU-vs-truth figures on the STORED truth set are appended to it; the caller hands the
+    list of all channels to tests_truth.ratchet_check, the direct bar at the accuracy this solver has (the bars in here are
+    relative to the reference's own error and would let the solver lose orders of magnitude next to zero unnoticed)."""
     lam = np.max(np.abs(Eref))
+    if stats is not None and truth is not None:
+        stats.append(truth_stats(E, Eref, truth[0], truth[1]))
     d = np.abs(E - Eref)
     rel = d / np.abs(Eref)
     exc = np.where(rel > 1e-10)[0]
@@ -75,12 +81,15 @@ def test_spectra_vs_reference(name):
     assert np.all(info == 0)
     lin = inp.kind_grid == 0
     truth = load_truth(name) if os.path.exists(os.path.join(ROOT, "tests", "golden", "truth_%s.npz" % name)) else {}
+    stats = []
     for l in range(lmax + 1):
         rel, nrm = figures(E[l], g["E"][l])
         note("solve %s l=%d n=%d: rel %.2e normwise %.2e  timing %s" % (name, l, prob.nfun, rel, nrm, prob.last_timing()))
         assert nrm <= 1e-13
         if lin:
-            full_size_bar(E[l], g["E"][l], "  bar %s l=%d" % (name, l), truth.get(l))
+            full_size_bar(E[l], g["E"][l], "  bar %s l=%d" % (name, l), truth.get(l), stats=stats)
+    if stats:
+        note(ratchet_check(name, stats))
     prob.close()
 
 
@@ -236,12 +245,14 @@ def test_c4_channels_at_full_size():
     E, info = prob.solve(0, 2)
     assert np.all(info == 0)
     truth = load_truth("c4_4096")
+    stats = []
     for l in range(2):
-        full_size_bar(E[l], g["E"][l], "solve c4_4096 l=%d" % l, truth[l])
+        full_size_bar(E[l], g["E"][l], "solve c4_4096 l=%d" % l, truth[l], stats=stats)
         # truth check: the GPU spectrum is at least as close to the exact Rydberg values as the reference's
         nq = np.arange(1, 11) + l
         exact = -0.5 / nq ** 2
         assert np.max(np.abs(E[l, :10] - exact)) <= np.max(np.abs(g["E"][l, :10] - exact)) + 1e-13
+    note(ratchet_check("c4_4096", stats))
     prob.close()
 
 
@@ -466,7 +477,9 @@ def test_c5_at_full_size():
     E, info = prob.solve(0, 1)
     assert np.all(info == 0)
     note("c5_8192 timing %s" % prob.last_timing())
-    full_size_bar(E[0], g["E"][0], "solve c5_8192 l=0", load_truth("c5_8192")[0])
+    stats = []
+    full_size_bar(E[0], g["E"][0], "solve c5_8192 l=0", load_truth("c5_8192")[0], stats=stats)
+    note(ratchet_check("c5_8192", stats))
     prob.close()
 
 
@@ -486,11 +499,13 @@ def test_variants_at_scale(name):
     E, info = prob.solve(0, nch)
     assert np.all(info == 0)
     truth = load_truth(name)
+    stats = []
     for l in range(nch):
         tag = "solve %s l=%d n=%d" % (name, l, prob.nfun)
         if inp.kind_grid == 0:
-            full_size_bar(E[l], g["E"][l], tag, truth[l])
+            full_size_bar(E[l], g["E"][l], tag, truth[l], stats=stats)
         else:
+            stats.append(truth_stats(E[l], g["E"][l], truth[l][0], truth[l][1]))
             lam = np.max(np.abs(g["E"][l]))
             idx, tru = truth[l]
             eg = np.abs(E[l][idx] - tru); er = np.abs(g["E"][l][idx] - tru)
@@ -500,6 +515,7 @@ def test_variants_at_scale(name):
                     np.max(er / np.abs(tru)), er.max(), er.max() / (np.finfo(float).eps * lam)))
             assert np.max(np.abs(E[l] - g["E"][l])) <= 1e-13 * lam
             assert np.all(eg <= 1e-10 * np.abs(tru) + 2.0 * np.maximum(er, np.max(er[near])))
+    note(ratchet_check(name, stats, linear=inp.kind_grid == 0))
     prob.close()
 
 
@@ -893,8 +909,10 @@ def test_c3_at_full_size_all_channels():
     assert np.all(info == 0)
     note("c3_2048_l31 timing %s -> %.1f eigensolves/s" % (prob.last_timing(), 32e3 / prob.last_timing()["total"]))
     truth = load_truth("c3_2048_l31")
+    stats = []
     for l in range(32):
-        full_size_bar(E[l], g["E"][l], "solve c3_2048_l31 l=%d" % l, truth[l])
+        full_size_bar(E[l], g["E"][l], "solve c3_2048_l31 l=%d" % l, truth[l], stats=stats)
+    note(ratchet_check("c3_2048_l31", stats))
     c = prob.eigvec(inp.l_ini, inp.n0_ini)
     r, u = prob.write_wf(c)
     rows = g["wf_rows"]; idx = g["wf_idx"]
@@ -932,8 +950,11 @@ def test_c4_all_128_channels_vs_reference():
             return hi
         return judge
 
+    stats = []
     for l in range(128):
-        full_size_bar(E[l], g["E"][l], "solve c4_4096_l127 l=%d" % l, truth[l], judge_for(l))
+        full_size_bar(E[l], g["E"][l], "solve c4_4096_l127 l=%d" % l, truth[l], judge_for(l), stats=stats)
+    # the direct bar: round 2 measured 57 eigenvalues of 524 288 beyond 1e-10 relative of the truth, worst 3.5e-9
+    note(ratchet_check("c4_4096_l127", stats))
     prob.close()
 
 
@@ -970,6 +991,14 @@ def test_fortran_host_full_stdout(tmp_path, name):
     # KIND_PI >= 3: MATRIX_SVT first calls ZINT_TH (angular integrals of the beam branches, outside SURVEY 8), which announces
     # itself; the host does not compute them and does not print their line
     ref = [l for l in ref if not l.startswith("REF_") and l != "Calculating Integrals Over th"]
+    if name.startswith("pi8"):
+        # KIND_PI >= 8: READ_INPUTS re-derives the field layer's pump / probe parameters (ReadInputs.f90:236-253) and prints four
+        # 'Modified ...' lines and an Eprobe from them; the field layer is outside SURVEY 8 (its keys are accepted, nothing is
+        # computed from them), the host does not reproduce that arithmetic (round-2 verdict: scope hygiene)
+        ref = [l for l in ref if not l.startswith("Modified ")]
+        assert len(mine) == len(ref)
+        keep = [i for i, l in enumerate(ref) if not l.startswith("Eprobe =")]
+        mine = [mine[i] for i in keep]; ref = [ref[i] for i in keep]
     eig = re.compile(r"^\s+(\d+)\s+(-?\d*\.\d+(E[+-]\d+)?)$")
     assert len(mine) == len(ref), "\n".join(mine[:60]) + "\n---\n" + "\n".join(ref[:60])
     for a, b in zip(mine, ref):
