@@ -34,7 +34,7 @@ class Sizes(C.Structure):
 EXPORTS = ["bspatom_input_defaults", "bspatom_device_count", "bspatom_host_setup", "bspatom_problem_create", "bspatom_problem_destroy",
            "bspatom_problem_sizes", "bspatom_problem_grid", "bspatom_assemble", "bspatom_solve", "bspatom_solve_dev",
            "bspatom_eigvec", "bspatom_eigvecs", "bspatom_dipole_bands", "bspatom_dipole_elements", "bspatom_write_wf", "bspatom_last_timing", "bsp_dsygv_", "bspatom_stage_gemm",
-           "bspatom_stage_standard_form", "bspatom_stage_sy2sb", "bspatom_stage_sb2st", "bspatom_stage_sb2sb", "bspatom_stage_bisect",
+           "bspatom_stage_standard_form", "bspatom_stage_sy2sb", "bspatom_stage_panel", "bspatom_stage_sb2st", "bspatom_stage_sb2sb", "bspatom_stage_bisect",
            "bspatom_set_option", "bspatom_get_option", "bspatom_kernel_times", "bspatom_kernel_slot_name"]
 
 _lib = None
@@ -70,6 +70,7 @@ def lib():
         L.bspatom_stage_standard_form.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp]
         L.bspatom_stage_sy2sb.argtypes = [i32, i32, vp, vp]
         L.bspatom_stage_sb2st.argtypes = [i32, i32, i32, vp, vp, vp]
+        L.bspatom_stage_panel.argtypes = [i32, i32, i32, vp, vp, vp]
         L.bspatom_stage_sb2sb.argtypes = [i32, i32, i32, vp]
         L.bspatom_stage_bisect.argtypes = [i32, i32, vp, vp, vp]
         L.bsp_dsygv_.restype = None
@@ -240,6 +241,17 @@ def stage_sy2sb(A):
     AB = np.zeros((batch, npad, 128))
     _chk(lib().bspatom_stage_sy2sb(npad, batch, _p(Af), _p(AB)), "bspatom_stage_sy2sb")
     return AB
+
+
+def stage_panel(A, c0):
+    """Panel factorisation of sy2sb alone.  A: (batch, npad, npad), any matrix (only the panel A[:, c0+64:, c0:c0+64] is touched).
+    Returns (A with the panel replaced by [R; 0], V (batch, m, 64), W (batch, m, 64))."""
+    batch, npad, _ = A.shape
+    m = npad - c0 - 64
+    Af = np.ascontiguousarray(A.transpose(0, 2, 1))      # column-major per matrix
+    V = np.zeros((batch, 64, m)); W = np.zeros((batch, 64, m))
+    _chk(lib().bspatom_stage_panel(npad, c0, batch, _p(Af), _p(V), _p(W)), "bspatom_stage_panel")
+    return Af.transpose(0, 2, 1), V.transpose(0, 2, 1), W.transpose(0, 2, 1)
 
 
 def stage_sb2st(AB, n):

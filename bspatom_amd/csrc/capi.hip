@@ -748,6 +748,35 @@ extern "C" int bspatom_stage_sy2sb(int npad, int batch, const double *A, double 
     return BSP_OK;
 }
 
+extern "C" int bspatom_stage_panel(int npad, int c0, int batch, double *A, double *V, double *W)
+{
+    int rc;
+    if ((rc = need_gpu())) return rc;
+    if (npad % 64 || c0 % 64 || c0 + 128 > npad || batch < 1) return BSP_ERR_ARG;
+    const int m = npad - c0 - 64;
+    DevBuf dA;
+    if ((rc = dA.put(A, (size_t)batch * npad * npad))) return rc;
+    void *work = nullptr;
+    BSP_HIP(hipMalloc(&work, sy2sb_work_bytes(npad, 64, batch)));
+    BSP_HIP(hipMemset(work, 0, sy2sb_work_bytes(npad, 64, batch)));
+    Sy2sbWork w;
+    sy2sb_carve(work, npad, 64, batch, &w);
+    rc = sy2sb_panel_only(npad, c0, batch, dA.p, w, 0);
+    hipError_t e = hipDeviceSynchronize();
+    if (!rc && e == hipSuccess) {
+        for (int b = 0; b < batch && e == hipSuccess; ++b)
+            for (int c = 0; c < 64 && e == hipSuccess; ++c) {          // column c of V (first slot of [V | Z | V]) and of W, rows 0 .. m-1
+                e = hipMemcpy(V + ((size_t)b * 64 + c) * m, w.buf + (size_t)b * npad * 192 + (size_t)c * npad, (size_t)m * sizeof(double), hipMemcpyDeviceToHost);
+                if (e == hipSuccess)
+                    e = hipMemcpy(W + ((size_t)b * 64 + c) * m, w.W + (size_t)b * npad * 64 + (size_t)c * npad, (size_t)m * sizeof(double), hipMemcpyDeviceToHost);
+            }
+    }
+    hipFree(work);
+    if (rc) return rc;
+    BSP_HIP(e);
+    return dA.get(A, (size_t)batch * npad * npad);
+}
+
 extern "C" int bspatom_stage_sb2st(int n, int npad, int batch, const double *AB, double *d, double *e)
 {
     int rc;

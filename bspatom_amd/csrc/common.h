@@ -45,7 +45,8 @@ struct Options {
     int sb2st_force_abort = 0;   // test hook: 1 = every ring ABORTs its handshake (member 0 runs alone); 2 = pretend the
                                  // members sit on different XCDs (same fallback through the other branch)
     int sy2sb_groups = 2, sy2sb_lookahead = 1, sy2sb_segs = 0;
-    int panel_qr = 2;            // BSP_PANEL_QR: 1 = first panel kernel for every panel (it always serves panels above 4096 rows)
+    int panel_qr = 3;            // BSP_PANEL_QR: 3 = TSQR + Householder reconstruction on many workgroups (tsqr.hip); 2 = one workgroup per
+                                 // channel with LDS-DMA (n <= 8256; above 4096 rows it falls back to 1), 1 = the first panel kernel
     int gemm_diag = 0;
     int bisect = 3, bisect_ept = 0;
     int bisect_tail = 1;         // BSP_BISECT_TAIL: 0 = lock-step bisection to the end (no multisection tail), for A/B timing
@@ -129,7 +130,13 @@ int launch_band_cholesky(int n, int k, const double *d_SB, double *d_UB, double 
 int launch_standard_form(int n, int npad, int k, int nl, const double *d_HB, const double *d_UB,
                          const double *d_rdiag, double *d_Y, double *d_C, hipStream_t st, int full = 0);
 // sy2sb.hip
+// tsqr.hip: panel factorisation on many workgroups (TSQR + Householder reconstruction), BSP_PANEL_QR=3
+long tsqr_scr_doubles(int npad);
+long tsqr_cntr_ints(int npad);
+int tsqr_panel(int npad, int r0, int c0, int batch, double *d_A, double *buf, double *W, double *scr, int *cntr, hipStream_t st);
 struct Sy2sbWork {
+    double *tsqr_scr;   // [batch][tsqr_scr_doubles(npad)]
+    int *tsqr_cntr;     // [batch][tsqr_cntr_ints(npad)], zeroed at the start of every sy2sb_run
     double *buf2;   // second [V | Z | V] set (panels alternate: look-ahead QR writes one while the update reads the other)
     double *tau2;
     double *buf;    // [batch][npad][3*nb]  : [V | Z | V]
@@ -144,6 +151,7 @@ constexpr int SY2SB_SPLITK = 16;
 size_t sy2sb_work_bytes(int npad, int nb, int batch);
 void sy2sb_carve(void *base, int npad, int nb, int batch, Sy2sbWork *w);
 int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipStream_t st);
+int sy2sb_panel_only(int npad, int c0, int batch, double *d_A, const Sy2sbWork &w, hipStream_t st);
 int launch_extract_band(int npad, int nb, int batch, const double *d_A, double *d_AB, hipStream_t st);
 // sb2st.hip
 // ctl: device scratch of sb2st_ctl_bytes(batch) bytes owned by the caller (per problem); nullptr -> a

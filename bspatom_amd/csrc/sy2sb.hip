@@ -564,6 +564,7 @@ size_t sy2sb_work_bytes(int npad, int nb, int batch)
 {
     (void)nb;
     size_t per = 2 * ((size_t)npad * 3 * NB + NB) + (size_t)npad * NB + (3 + SY2SB_SPLITK) * NB * NB;
+    per += (size_t)tsqr_scr_doubles(npad) + ((size_t)tsqr_cntr_ints(npad) + 1) / 2;
     return per * batch * sizeof(double);
 }
 
@@ -579,7 +580,9 @@ void sy2sb_carve(void *base, int npad, int nb, int batch, Sy2sbWork *w)
     w->Kmat = p; p += (size_t)batch * NB * NB;
     w->tau = p; p += (size_t)batch * NB;
     w->tau2 = p; p += (size_t)batch * NB;
-    w->part = p;
+    w->part = p; p += (size_t)batch * SY2SB_SPLITK * NB * NB;
+    w->tsqr_scr = p; p += (size_t)batch * tsqr_scr_doubles(npad);
+    w->tsqr_cntr = reinterpret_cast<int *>(p);
 }
 
 template <int RPT>
@@ -607,6 +610,9 @@ static int panel_and_W(int npad, int c0, int batch, double *d_A, double *buf, do
 {
     const int r0 = c0 + NB, m = npad - r0;
     const long bsBuf = (long)npad * 3 * NB, bsW = (long)npad * NB, bsS = NB * NB;
+    (void)tau;
+    if (opts().panel_qr >= 3) return tsqr_panel(npad, r0, c0, batch, d_A, buf, w.W, w.tsqr_scr, w.tsqr_cntr, s);
+    if (m > PQ_THREADS * 16) return BSP_ERR_UNSUPPORTED;              // one workgroup holds 16 rows per thread: n <= 8256
     const int rpt = (m + PQ_THREADS - 1) / PQ_THREADS;
     if (rpt <= 1) launch_pq<1>(npad, r0, c0, batch, d_A, buf, tau, s);
     else if (rpt <= 2) launch_pq<2>(npad, r0, c0, batch, d_A, buf, tau, s);
@@ -628,6 +634,14 @@ static int panel_and_W(int npad, int c0, int batch, double *d_A, double *buf, do
     BSP_HIP(hipGetLastError());
     // W = V T   (m x 64 times 64 x 64)
     return tsmm64_f64(m, batch, buf, npad, bsBuf, w.T, bsS, w.W, npad, bsW, 1.0, 0.0, s);
+}
+
+// stage-level entry (tests): the panel factorisation alone, for the panel whose columns start at c0
+int sy2sb_panel_only(int npad, int c0, int batch, double *d_A, const Sy2sbWork &w, hipStream_t st)
+{
+    if (npad % NB || c0 % NB || c0 + 2 * NB > npad) return BSP_ERR_ARG;
+    if (opts().panel_qr >= 3) BSP_HIP(hipMemsetAsync(w.tsqr_cntr, 0, (size_t)batch * tsqr_cntr_ints(npad) * sizeof(int), st));
+    return panel_and_W(npad, c0, batch, d_A, w.buf, w.tau, w, st);
 }
 
 // Look-ahead schedule: after the block column that holds the next panel has been updated (syr2k
@@ -714,7 +728,8 @@ static int sy2sb_pipeline(int npad, int batch, double *d_A, const Sy2sbWork &w, 
 int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipStream_t st)
 {
     if (nb != NB || npad % NB != 0) return BSP_ERR_ARG;
-    if (npad - NB > PQ_THREADS * 16) return BSP_ERR_UNSUPPORTED;   // n <= 8256
+    if (opts().panel_qr < 3 && npad - NB > PQ_THREADS * 16) return BSP_ERR_UNSUPPORTED;   // the one-workgroup panel kernels: n <= 8256
+    if (opts().panel_qr >= 3) BSP_HIP(hipMemsetAsync(w.tsqr_cntr, 0, (size_t)batch * tsqr_cntr_ints(npad) * sizeof(int), st));
     constexpr int MAXG = 4;
     static Sy2sbLane lanes[MAXG];
     static hipEvent_t fork = nullptr;
@@ -755,6 +770,8 @@ int sy2sb_run(int npad, int nb, int batch, double *d_A, const Sy2sbWork &w, hipS
         wg[g].G = w.G + c0 * bsS; wg[g].T = w.T + c0 * bsS; wg[g].Kmat = w.Kmat + c0 * bsS;
         wg[g].tau = w.tau + (size_t)c0 * NB; wg[g].tau2 = w.tau2 + (size_t)c0 * NB;
         wg[g].part = w.part + (size_t)c0 * SY2SB_SPLITK * bsS;      // [splits][cnt][nb][nb] inside this group's share
+        wg[g].tsqr_scr = w.tsqr_scr + (size_t)c0 * tsqr_scr_doubles(npad);
+        wg[g].tsqr_cntr = w.tsqr_cntr + (size_t)c0 * tsqr_cntr_ints(npad);
         BSP_HIP(hipStreamWaitEvent(lanes[g].main, fork, 0));
         c0 += cnt[g];
     }

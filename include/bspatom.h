@@ -152,6 +152,10 @@ int bspatom_stage_standard_form(int n, int k, int nl, const double *SB, const do
                                 double *C, int32_t *info);
 /* dense symmetric (npad multiple of 64, full storage) -> lower band AB[d + j*128], d <= 64 */
 int bspatom_stage_sy2sb(int npad, int batch, const double *A, double *AB);
+/* the panel factorisation of sy2sb alone (tests): panel = A[c0+64 .., c0 .. c0+63] of each dense npad x npad matrix (column-major).
+ * On return the panel holds [R; 0]; V[b][c][0..m-1], W[b][c][0..m-1] (m = npad - c0 - 64) with I - V T V^T = I - W V^T orthogonal and
+ * (I - W V^T)^T panel = [R; 0].  The panel QR inside LAPACK DSYTRD's blocked reduction (matrices.f90:248). */
+int bspatom_stage_panel(int npad, int c0, int batch, double *A, double *V, double *W);
 /* band (AB as above, leading n x n) -> tridiagonal d[n], e[n-1] (ld npad) */
 int bspatom_stage_sb2st(int n, int npad, int batch, const double *AB, double *d, double *e);
 /* first half of the two-step route (sb2st_version 9): band 64 -> band 16 in place, same layout */

@@ -161,6 +161,60 @@ def test_sy2sb(npad, batch):
         assert np.max(np.abs(AB[b][:, 65:])) == 0.0
 
 
+@pytest.mark.parametrize("panel_qr", [3, 2])
+@pytest.mark.parametrize("npad,c0,kind", [(128, 0, "rand"), (192, 0, "rand"), (256, 0, "rand"), (320, 0, "rand"), (384, 64, "rand"),
+                                          (1152, 0, "graded"), (1152, 64, "rand"), (4096, 0, "rand"), (4160, 0, "graded"),
+                                          (640, 0, "rankdef"), (2048, 1472, "zero")])
+def test_panel_factorisation(npad, c0, kind, panel_qr):
+    """The panel factorisation of sy2sb alone (csrc/tsqr.hip: TSQR on many workgroups + Householder reconstruction,
+    BSP_PANEL_QR=3; csrc/sy2sb.hip::panel_qr2_kernel + G + T + W, BSP_PANEL_QR=2) against its defining properties, as
+    tools/proto_tsqr.py states them:  Q = I - W V^T (W = V T) orthogonal,  Q^T P = [R; 0] with R upper triangular = what the kernel
+    left in the panel,  zeros below R.  Sizes: one block (m <= 256), one tree level (m <= 1024), two levels (m = 4032, 4096),
+    ragged last blocks; a panel graded over 12 decades, one with 24 zero columns and zero padding rows (H = I reflectors), and an
+    all-zero panel.  Tolerances: a few ulp of ||P|| times sqrt(m)."""
+    rng = np.random.default_rng(npad + c0)
+    batch = 2
+    m = npad - c0 - 64
+    A = rng.standard_normal((batch, npad, npad))
+    P = rng.standard_normal((batch, m, 64))
+    if kind == "graded":
+        for b in range(batch):
+            u, sv, vt = np.linalg.svd(P[b], full_matrices=False)
+            P[b] = (u * np.logspace(0, -12, 64)) @ vt
+    if kind == "rankdef":
+        P[:, :, 40:] = 0.0
+        P[:, m - 40:, :] = 0.0
+    if kind == "zero":
+        P[:] = 0.0
+    A[:, c0 + 64:, c0:c0 + 64] = P
+    A0 = A.copy()
+    old = capi.get_option("panel_qr")
+    capi.set_option("panel_qr", panel_qr)
+    try:
+        A1, V, W = capi.stage_panel(A, c0)
+    finally:
+        capi.set_option("panel_qr", old)
+    # nothing but the panel is touched
+    mask = np.ones((npad, npad), dtype=bool); mask[c0 + 64:, c0:c0 + 64] = False
+    assert np.array_equal(A1[:, mask], A0[:, mask])
+    for b in range(batch):
+        Pn = A1[b, c0 + 64:, c0:c0 + 64]
+        R = Pn[:64]
+        scale = max(np.max(np.abs(P[b])), 1e-300)
+        assert np.all(np.tril(R, -1) == 0.0) and np.all(Pn[64:] == 0.0)
+        Q = np.eye(m) - W[b] @ V[b].T
+        e_orth = np.max(np.abs(Q.T @ Q - np.eye(m)))
+        QtP = Q.T @ P[b]
+        e_fact = np.max(np.abs(QtP[:64] - R)) / scale
+        e_zero = np.max(np.abs(QtP[64:])) / scale if m > 64 else 0.0
+        note("panel qr=%d npad %d c0 %d %s b%d: orthogonality %.1e  Q^T P - [R;0] %.1e / %.1e  max|V| %.2f max|W| %.2f"
+             % (panel_qr, npad, c0, kind, b, e_orth, e_fact, e_zero, np.max(np.abs(V[b])), np.max(np.abs(W[b]))))
+        tol = 4e-15 * np.sqrt(m) + 2e-14
+        assert e_orth < tol and e_fact < tol and e_zero < tol
+        # V is unit lower trapezoidal (exactly: ones and zeros are stored as such)
+        assert np.all(np.triu(V[b, :64], 1) == 0.0) and np.all(np.diag(V[b, :64]) == 1.0)
+
+
 @pytest.mark.parametrize("n,npad,batch", [(128, 128, 1), (250, 256, 2), (700, 704, 2)])
 def test_sb2st(n, npad, batch):
     from scipy.linalg import eigvalsh_tridiagonal
