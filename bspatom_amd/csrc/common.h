@@ -47,6 +47,9 @@ struct Options {
     int sy2sb_groups = 2, sy2sb_lookahead = 1, sy2sb_segs = 0;
     int panel_qr = 3;            // BSP_PANEL_QR: 3 = TSQR + Householder reconstruction on many workgroups (tsqr.hip); 2 = one workgroup per
                                  // channel with LDS-DMA (n <= 8256; above 4096 rows it falls back to 1), 1 = the first panel kernel
+    int tsqr_max_m = 2048;       // BSP_TSQR_MAX_M: panels with more rows than this (and at most 8192) take the one-workgroup kernel (0 = no limit); a rule in m alone,
+                                 // so the arithmetic does not depend on the batch size
+    int tsqr_regcap = 1;         // BSP_TSQR_REGCAP: 1 = the 256-register variants of the tsqr.hip kernels (they fit beside one GEMM workgroup), 0 = uncapped
     int gemm_diag = 0;
     int bisect = 3, bisect_ept = 0;
     int bisect_tail = 1;         // BSP_BISECT_TAIL: 0 = lock-step bisection to the end (no multisection tail), for A/B timing

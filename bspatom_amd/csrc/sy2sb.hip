@@ -588,7 +588,7 @@ void sy2sb_carve(void *base, int npad, int nb, int batch, Sy2sbWork *w)
 template <int RPT>
 static void launch_pq(int npad, int r0, int c0, int batch, double *A, double *buf, double *tau, hipStream_t st)
 {
-    const int use2 = opts().panel_qr == 2;
+    const int use2 = opts().panel_qr >= 2;
     KScope kt(KS_PANEL_QR, st);
     if (use2 && RPT <= 8) {
         const size_t lds = (size_t)(2 * CW2 * PQ_THREADS * RPT + 128) * sizeof(double);
@@ -611,7 +611,8 @@ static int panel_and_W(int npad, int c0, int batch, double *d_A, double *buf, do
     const int r0 = c0 + NB, m = npad - r0;
     const long bsBuf = (long)npad * 3 * NB, bsW = (long)npad * NB, bsS = NB * NB;
     (void)tau;
-    if (opts().panel_qr >= 3) return tsqr_panel(npad, r0, c0, batch, d_A, buf, w.W, w.tsqr_scr, w.tsqr_cntr, s);
+    if (opts().panel_qr >= 3 && (opts().tsqr_max_m <= 0 || m <= opts().tsqr_max_m || m > PQ_THREADS * 16))
+        return tsqr_panel(npad, r0, c0, batch, d_A, buf, w.W, w.tsqr_scr, w.tsqr_cntr, s);
     if (m > PQ_THREADS * 16) return BSP_ERR_UNSUPPORTED;              // one workgroup holds 16 rows per thread: n <= 8256
     const int rpt = (m + PQ_THREADS - 1) / PQ_THREADS;
     if (rpt <= 1) launch_pq<1>(npad, r0, c0, batch, d_A, buf, tau, s);

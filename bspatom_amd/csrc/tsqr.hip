@@ -49,7 +49,7 @@ struct TsqrArgs {
     double *W; long bsW;               // W = V T, ld = npad
     double *scr; long bsScr;           // scratch per channel: Q blocks | R blocks | U^-1 | T | L | S'
     int *cntr; long bsCntr;            // arrival counters per node (zero between launches)
-    long offQ, offR, offUi, offT, offL, offS;
+    long offQ, offR, offUi, offT, offS;
     TsqrPlan plan;
 };
 
@@ -77,92 +77,130 @@ __device__ __forceinline__ void tq_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\
 // ---- the 256 x 64 block in registers: thread (rg = lane & 15, cg = tid >> 4) holds a[i][jj] = element (rg + 16 i, cg + 16 jj).
 // Column j = 16 JJ + j16 lives in register column JJ of the 16 threads with cg == j16 (one DPP row); rows < 16 JJ are finished.
 
-// Householder QR, columns 16 JJ .. 16 JJ + 15: afterwards R on and above the diagonal, the reflectors (unit diagonal implied)
-// below it, tau in taus[].  Nothing (numerically) below a pivot: H = I, tiny entries are dropped (as sy2sb.hip's panel kernels do).
+// Update of register column block jj with the reflector (v, tau): a(:, jj) -= tau (v^T a(:, jj)) v for the rows of blocks >= I0,
+// wherever `on` (a whole DPP row is on or off: its 16 lanes hold one column).  Branch-free: a row that is off subtracts zero.
+#define TQ_UPD(I0, JJX, ON)                                                                 \
+    {                                                                                       \
+        double s0_ = 0.0, s1_ = 0.0;                                                        \
+        _Pragma("unroll") for (int i = (I0); i < 16; ++i) {                                 \
+            if (i & 1) s1_ += v[i] * a[i][JJX]; else s0_ += v[i] * a[i][JJX];               \
+        }                                                                                   \
+        const double w_ = (ON) ? tau * tq_rsum16(s0_ + s1_) : 0.0;                          \
+        _Pragma("unroll") for (int i = (I0); i < 16; ++i) a[i][JJX] -= w_ * v[i];           \
+    }
+
+// Householder vector of column jn = 16 JN + jn16 (held by the 16 lanes with cg == jn16 in register column JN).  The arithmetic runs on
+// ALL lanes, each on its own column (the other rows' results are discarded): no branch around the long dependent chain (norm,
+// sqrt, two divisions), so that the scheduler fills it with the independent column updates that follow in the same block.
+// Nothing (numerically) below the pivot: H = I, tiny entries are dropped (as sy2sb.hip's panel kernels do).
+template <int JN>
+__device__ __forceinline__ void tq_house(double (&a)[16][4], int jn16, double *vn, double *taus, int rg, int cg)
+{
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int i = JN + 1; i < 16; ++i) {
+        if (i & 1) s1 += a[i][JN] * a[i][JN]; else s0 += a[i][JN] * a[i][JN];
+    }
+    const double x0 = a[JN][JN];
+    const double sigma = tq_rsum16((s0 + s1) + (rg > jn16 ? x0 * x0 : 0.0));
+    const double alpha = tq_rsum16(rg == jn16 ? x0 : 0.0);
+    const double n2 = alpha * alpha + sigma;
+    const bool ok = sigma != 0.0 && n2 > 1e-280;
+    const double nrm = sqrt(ok ? n2 : 1.0);
+    const double beta = ok ? -copysign(nrm, alpha) : alpha;
+    double tau = ok ? (beta - alpha) / (ok ? beta : 1.0) : 0.0;
+    double scale = ok ? 1.0 / (ok ? alpha - beta : 1.0) : 0.0;
+    asm volatile("" : "+v"(tau), "+v"(scale));           // computed here, not inside the branch below
+    if (cg == jn16) {
+#pragma unroll
+        for (int i = JN + 1; i < 16; ++i) {
+            a[i][JN] *= scale;
+            vn[rg + 16 * i] = a[i][JN];
+        }
+        const double xs = x0 * scale;
+        vn[rg + 16 * JN] = rg > jn16 ? xs : (rg == jn16 ? 1.0 : 0.0);
+        a[JN][JN] = rg > jn16 ? xs : (rg == jn16 ? beta : x0);
+        if (rg == 0) taus[16 * JN + jn16] = tau;
+    }
+}
+
+// One column step j = 16 JJ + j16 of the QR: apply H_j (its v, tau are in LDS since the previous step) -- first to the register
+// column block JN that holds column j + 1, then form v_{j+1} there (look-ahead: the only thing the next step waits for), then
+// the other blocks.  One LDS-only barrier per column.
+template <int JJ, int JN, bool NEXT>
+__device__ __forceinline__ void tq_qr_step(double (&a)[16][4], double *vb, double *taus, int j16, int rg, int cg)
+{
+    const int j = 16 * JJ + j16;
+    const double *vp = vb + (j & 1) * TR;
+    double *vn = vb + ((j + 1) & 1) * TR;
+    const double tau = taus[j];
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = i >= JJ ? vp[rg + 16 * i] : 0.0;
+    const bool onJ = cg > j16;                            // block JJ: the columns right of j
+    if constexpr (JN == JJ) TQ_UPD(JJ, JJ, onJ)
+    else if constexpr (JN < 4) TQ_UPD(JJ, JN, true)
+    if constexpr (NEXT) tq_house<(JN < 4 ? JN : 3)>(a, (j16 + 1) & 15, vn, taus, rg, cg);
+#pragma unroll
+    for (int jj = JJ; jj < 4; ++jj) {
+        if (jj == JN) continue;
+        if (jj == JJ) TQ_UPD(JJ, JJ, onJ)
+        else TQ_UPD(JJ, jj, true)
+    }
+    tq_bar();
+}
+
 template <int JJ>
 __device__ __forceinline__ void tq_qr_cols(double (&a)[16][4], double *vb, double *taus, int rg, int cg)
 {
 #pragma unroll 1
-    for (int j16 = 0; j16 < 16; ++j16) {
-        const int j = 16 * JJ + j16;
-        double *vp = vb + (j & 1) * TR;
-        if (cg == j16) {
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int i = JJ + 1; i < 16; ++i) {
-                if (i & 1) s1 += a[i][JJ] * a[i][JJ]; else s0 += a[i][JJ] * a[i][JJ];
-            }
-            const double x0 = a[JJ][JJ];
-            const double sigma = tq_rsum16((s0 + s1) + (rg > j16 ? x0 * x0 : 0.0));
-            const double alpha = tq_rsum16(rg == j16 ? x0 : 0.0);
-            double beta = alpha, tau = 0.0, scale = 0.0;
-            if (sigma != 0.0 && (alpha * alpha + sigma > 1e-280)) {
-                beta = -copysign(sqrt(alpha * alpha + sigma), alpha);
-                tau = (beta - alpha) / beta;
-                scale = 1.0 / (alpha - beta);
-            }
-#pragma unroll
-            for (int i = JJ + 1; i < 16; ++i) {
-                a[i][JJ] *= scale;
-                vp[rg + 16 * i] = a[i][JJ];
-            }
-            const double xs = x0 * scale;
-            vp[rg + 16 * JJ] = rg > j16 ? xs : (rg == j16 ? 1.0 : 0.0);
-            a[JJ][JJ] = rg > j16 ? xs : (rg == j16 ? beta : x0);
-            if (rg == 0) taus[j] = tau;
-        }
-        tq_bar();
-        const double tau = taus[j];
-        double v[16];
-#pragma unroll
-        for (int i = JJ; i < 16; ++i) v[i] = vp[rg + 16 * i];
-#pragma unroll
-        for (int jj = JJ; jj < 4; ++jj) {
-            if (jj > JJ || cg > j16) {                 // columns right of j (a DPP row is all in or all out)
-                double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                for (int i = JJ; i < 16; ++i) {
-                    if (i & 1) s1 += v[i] * a[i][jj]; else s0 += v[i] * a[i][jj];
-                }
-                const double w = tau * tq_rsum16(s0 + s1);
-#pragma unroll
-                for (int i = JJ; i < 16; ++i) a[i][jj] -= w * v[i];
-            }
-        }
-    }
+    for (int j16 = 0; j16 < 15; ++j16) tq_qr_step<JJ, JJ, true>(a, vb, taus, j16, rg, cg);
+    tq_qr_step<JJ, JJ + 1, (JJ < 3)>(a, vb, taus, 15, rg, cg);
+}
+
+// Householder QR of the block: afterwards R on and above the diagonal, the reflectors (unit diagonal implied) below it, tau in taus[].
+__device__ __forceinline__ void tq_qr(double (&a)[16][4], double *vb, double *taus, int rg, int cg)
+{
+    tq_house<0>(a, 0, vb, taus, rg, cg);
+    tq_bar();
+    tq_qr_cols<0>(a, vb, taus, rg, cg);
+    tq_qr_cols<1>(a, vb, taus, rg, cg);
+    tq_qr_cols<2>(a, vb, taus, rg, cg);
+    tq_qr_cols<3>(a, vb, taus, rg, cg);
 }
 
 // Explicit Q = H_0 H_1 .. H_63 [I; 0] in place of the reflectors (LAPACK dorg2r: last reflector first; column j becomes H_j e_j
-// after H_j has been applied to the columns right of it).
+// after H_j has been applied to the columns right of it).  v_{j-1} is published while step j runs (column j - 1 is not touched by
+// H_j), so a step is: read v_j, update, one barrier.
+template <int JP>
+__device__ __forceinline__ void tq_publish(const double (&a)[16][4], int jp16, double *vn, int rg, int cg)
+{
+    if (cg == jp16) {
+#pragma unroll
+        for (int i = JP + 1; i < 16; ++i) vn[rg + 16 * i] = a[i][JP];
+        vn[rg + 16 * JP] = rg > jp16 ? a[JP][JP] : (rg == jp16 ? 1.0 : 0.0);
+    }
+}
+
 template <int JJ>
 __device__ __forceinline__ void tq_formq_cols(double (&a)[16][4], double *vb, const double *taus, int rg, int cg)
 {
 #pragma unroll 1
     for (int j16 = 15; j16 >= 0; --j16) {
         const int j = 16 * JJ + j16;
-        double *vp = vb + (j & 1) * TR;
-        if (cg == j16) {
-#pragma unroll
-            for (int i = JJ + 1; i < 16; ++i) vp[rg + 16 * i] = a[i][JJ];
-            vp[rg + 16 * JJ] = rg > j16 ? a[JJ][JJ] : (rg == j16 ? 1.0 : 0.0);
-        }
-        tq_bar();
+        const double *vp = vb + (j & 1) * TR;
+        double *vn = vb + ((j + 1) & 1) * TR;             // (j - 1) & 1
+        if (j16 > 0) tq_publish<JJ>(a, j16 - 1, vn, rg, cg);
+        else if (JJ > 0) tq_publish<(JJ > 0 ? JJ - 1 : 0)>(a, 15, vn, rg, cg);
         const double tau = taus[j];
         double v[16];
 #pragma unroll
-        for (int i = JJ; i < 16; ++i) v[i] = vp[rg + 16 * i];
+        for (int i = 0; i < 16; ++i) v[i] = i >= JJ ? vp[rg + 16 * i] : 0.0;
+        const bool onJ = cg > j16;
 #pragma unroll
         for (int jj = JJ; jj < 4; ++jj) {
-            if (jj > JJ || cg > j16) {
-                double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                for (int i = JJ; i < 16; ++i) {
-                    if (i & 1) s1 += v[i] * a[i][jj]; else s0 += v[i] * a[i][jj];
-                }
-                const double w = tau * tq_rsum16(s0 + s1);
-#pragma unroll
-                for (int i = JJ; i < 16; ++i) a[i][jj] -= w * v[i];
-            }
+            if (jj == JJ) TQ_UPD(JJ, JJ, onJ)
+            else TQ_UPD(JJ, jj, true)
         }
         if (cg == j16) {
 #pragma unroll
@@ -172,12 +210,24 @@ __device__ __forceinline__ void tq_formq_cols(double (&a)[16][4], double *vb, co
             }
             a[JJ][JJ] = rg > j16 ? -tau * v[JJ] : (rg == j16 ? 1.0 - tau : 0.0);
         }
+        tq_bar();
     }
+}
+
+__device__ __forceinline__ void tq_formq(double (&a)[16][4], double *vb, const double *taus, int rg, int cg)
+{
+    tq_publish<3>(a, 15, vb + TR, rg, cg);                // v_63 -> buffer 63 & 1 (the QR's last read of it is behind a barrier)
+    tq_bar();
+    tq_formq_cols<3>(a, vb, taus, rg, cg);
+    tq_formq_cols<2>(a, vb, taus, rg, cg);
+    tq_formq_cols<1>(a, vb, taus, rg, cg);
+    tq_formq_cols<0>(a, vb, taus, rg, cg);
 }
 
 constexpr int TQ_LDS_TREE = (2 * TR + TB + 8 + 2 * TB * XS) * 8;       // vb | taus | flag | X | Y  = 69 184 bytes
 
-__global__ __launch_bounds__(256) void tsqr_tree_kernel(TsqrArgs g)
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void tsqr_tree_kernel(TsqrArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) double tq_lds[];
     double *vb = tq_lds, *taus = vb + 2 * TR;
@@ -209,10 +259,7 @@ __global__ __launch_bounds__(256) void tsqr_tree_kernel(TsqrArgs g)
             for (int i = 0; i < 16; ++i) a[i][jj] = (row0 + rg + 16 * i < g.m) ? a[i][jj] : 0.0;
     }
     for (;;) {
-        tq_qr_cols<0>(a, vb, taus, rg, cg);
-        tq_qr_cols<1>(a, vb, taus, rg, cg);
-        tq_qr_cols<2>(a, vb, taus, rg, cg);
-        tq_qr_cols<3>(a, vb, taus, rg, cg);
+        tq_qr(a, vb, taus, rg, cg);
         double *Rn = Rall + (long)(pl.base[level] + node) * (TB * TB);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
@@ -221,10 +268,7 @@ __global__ __launch_bounds__(256) void tsqr_tree_kernel(TsqrArgs g)
                 const int r = rg + 16 * i, c = cg + 16 * jj;
                 Rn[r + TB * c] = r <= c ? a[i][jj] : 0.0;
             }
-        tq_formq_cols<3>(a, vb, taus, rg, cg);
-        tq_formq_cols<2>(a, vb, taus, rg, cg);
-        tq_formq_cols<1>(a, vb, taus, rg, cg);
-        tq_formq_cols<0>(a, vb, taus, rg, cg);
+        tq_formq(a, vb, taus, rg, cg);
         double *Qn = Qall + (long)(pl.base[level] + node) * (TR * TB);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
@@ -316,101 +360,160 @@ __global__ __launch_bounds__(256) void tsqr_tree_kernel(TsqrArgs g)
         }
     } else tq_bar();
 
-    // ---- modified LU of X = Q11 - S' (S' chosen on the fly), in place: L strictly below the diagonal, U on and above it
-    double *sg = vb;                                // the v buffers are free now
+    // ---- modified LU of X = Q11 - S' (S' chosen on the fly: s_j = -sgn of the partially eliminated diagonal, |pivot| >= 1), then
+    // T = -U S' L^-T and U^-1, all in REGISTERS: thread (br = tid & 15, bc = tid >> 4) owns the 4 x 4 block (rows 4 br.., columns
+    // 4 bc..) of each 64 x 64 matrix; per step the pivot row / column travel through LDS (double-buffered: one barrier per step).
+    // L is formed by multiplication with the reciprocal pivot, the same product wherever it is used.
+    const int br = tid & 15, bc = tid >> 4;
+    double x[4][4], t[4][4], ui[4][4];
+#pragma unroll
+    for (int ro = 0; ro < 4; ++ro)
+#pragma unroll
+        for (int co = 0; co < 4; ++co) x[ro][co] = X[(4 * br + ro) + XS * (4 * bc + co)];
+    double *sg = taus;                               // the tau's are not needed any more
+    double *Urow = vb, *Lcol = vb + 128;             // [2][64] each
 #pragma unroll 1
-    for (int j = 0; j < TB; ++j) {
-        const double d = X[j + XS * j];
-        const double s = d >= 0.0 ? -1.0 : 1.0;
-        const double piv = d - s;
-        if (tid > j && tid < TB) X[tid + XS * j] = X[tid + XS * j] / piv;
-        tq_bar();
-        if (tid == 0) { X[j + XS * j] = piv; sg[j] = s; }
-        // trailing update, thread t: rows r = j + 1 + (t & 15) + 16 a, columns c = j + 1 + (t >> 4) + 16 b
-        for (int c = j + 1 + (tid >> 4); c < TB; c += 16) {
-            const double ujc = X[j + XS * c];
-            for (int r = j + 1 + (tid & 15); r < TB; r += 16) X[r + XS * c] -= X[r + XS * j] * ujc;
+    for (int jb = 0; jb < 16; ++jb) {
+#pragma unroll
+        for (int jo = 0; jo < 4; ++jo) {
+            const int j = 4 * jb + jo, p = 64 * (jo & 1);
+            if (br == jb) {
+#pragma unroll
+                for (int co = 0; co < 4; ++co) Urow[p + 4 * bc + co] = x[jo][co];
+            }
+            if (bc == jb) {
+#pragma unroll
+                for (int ro = 0; ro < 4; ++ro) Lcol[p + 4 * br + ro] = x[ro][jo];
+            }
+            tq_bar();
+            const double d = Urow[p + j];
+            const double sj = d >= 0.0 ? -1.0 : 1.0;
+            const double piv = d - sj, rp = 1.0 / piv;
+            double lv[4], uv[4];
+#pragma unroll
+            for (int ro = 0; ro < 4; ++ro) lv[ro] = (4 * br + ro > j) ? Lcol[p + 4 * br + ro] * rp : 0.0;
+#pragma unroll
+            for (int co = 0; co < 4; ++co) uv[co] = (4 * bc + co > j) ? Urow[p + 4 * bc + co] : 0.0;
+#pragma unroll
+            for (int ro = 0; ro < 4; ++ro)
+#pragma unroll
+                for (int co = 0; co < 4; ++co) x[ro][co] -= lv[ro] * uv[co];
+            if (bc == jb) {
+#pragma unroll
+                for (int ro = 0; ro < 4; ++ro)
+                    if (4 * br + ro > j) x[ro][jo] = lv[ro];
+                if (br == jb) x[jo][jo] = piv;
+            }
+            if (tid == 0) sg[j] = sj;
         }
-        tq_bar();
-    }
-    // ---- Y = -U S' (upper triangle), then T = Y L^-T in place, row by row (thread i owns row i: T(i,c) -= sum_{k<c} T(i,k) L(c,k))
-    for (int idx = tid; idx < TB * TB; idx += 256) {
-        const int r = idx & 63, c = idx >> 6;
-        Y[r + XS * c] = r <= c ? -X[r + XS * c] * sg[c] : 0.0;
     }
     tq_bar();
-    double *Ui = scr + g.offUi, *Tm = scr + g.offT, *Lm = scr + g.offL, *Sm = scr + g.offS;
-    if (tid >= 64 && tid < 128) {                   // wave 1: T
-        const int i = tid - 64;
-        for (int c = i + 1; c < TB; ++c) {
-            double s = Y[i + XS * c];
-            for (int k = i; k < c; ++k) s -= Y[i + XS * k] * X[c + XS * k];
-            Y[i + XS * c] = s;
+    // t = Y = -U S' (upper triangle), ui = I;  then, in one loop of 64 steps: column c = it of T is final and leaves the columns
+    // right of it (T L^T = Y), row k = 63 - it of U^-1 is final and leaves the rows above it (U U^-1 = I)
+#pragma unroll
+    for (int ro = 0; ro < 4; ++ro)
+#pragma unroll
+        for (int co = 0; co < 4; ++co) {
+            const int r = 4 * br + ro, c = 4 * bc + co;
+            t[ro][co] = r <= c ? -x[ro][co] * sg[c] : 0.0;
+            ui[ro][co] = r == c ? 1.0 : 0.0;
+        }
+    double *Tcol = vb, *LcT = vb + 128, *Xrow = vb + 256, *Ucol = vb + 384;      // [2][64] each
+#pragma unroll 1
+    for (int cb = 0; cb < 16; ++cb) {
+        const int kb = 15 - cb;
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+            const int kj = 3 - cj;
+            const int c = 4 * cb + cj, k = 4 * kb + kj, p = 64 * (cj & 1);
+            if (bc == cb) {
+#pragma unroll
+                for (int ro = 0; ro < 4; ++ro) {
+                    Tcol[p + 4 * br + ro] = t[ro][cj];
+                    LcT[p + 4 * br + ro] = (4 * br + ro > c) ? x[ro][cj] : 0.0;          // L(r, c), r > c
+                }
+            }
+            if (br == kb) {
+#pragma unroll
+                for (int co = 0; co < 4; ++co) Xrow[p + 4 * bc + co] = ui[kj][co];
+            }
+            if (bc == kb) {
+#pragma unroll
+                for (int ro = 0; ro < 4; ++ro) Ucol[p + 4 * br + ro] = (4 * br + ro <= k) ? x[ro][kj] : 0.0;   // U(r, k), r <= k
+            }
+            tq_bar();
+            {
+                double tc[4], lc[4];
+#pragma unroll
+                for (int ro = 0; ro < 4; ++ro) tc[ro] = Tcol[p + 4 * br + ro];
+#pragma unroll
+                for (int co = 0; co < 4; ++co) lc[co] = (4 * bc + co > c) ? LcT[p + 4 * bc + co] : 0.0;
+#pragma unroll
+                for (int ro = 0; ro < 4; ++ro)
+#pragma unroll
+                    for (int co = 0; co < 4; ++co) t[ro][co] -= tc[ro] * lc[co];
+            }
+            {
+                const double rp = 1.0 / Ucol[p + k];
+                double xr[4], uc[4];
+#pragma unroll
+                for (int co = 0; co < 4; ++co) xr[co] = Xrow[p + 4 * bc + co] * rp;
+#pragma unroll
+                for (int ro = 0; ro < 4; ++ro) uc[ro] = (4 * br + ro < k) ? Ucol[p + 4 * br + ro] : 0.0;
+#pragma unroll
+                for (int ro = 0; ro < 4; ++ro)
+#pragma unroll
+                    for (int co = 0; co < 4; ++co) ui[ro][co] -= uc[ro] * xr[co];
+                if (br == kb) {
+#pragma unroll
+                    for (int co = 0; co < 4; ++co) ui[kj][co] = xr[co];
+                }
+            }
         }
     }
-    // L (unit lower) and S' to scratch while wave 1 works: X's lower triangle is not written any more
-    for (int idx = tid; idx < TB * TB; idx += 256) {
-        const int r = idx & 63, c = idx >> 6;
-        Lm[idx] = r > c ? X[r + XS * c] : (r == c ? 1.0 : 0.0);          // column-major, ld 64
-    }
+    // ---- results: U^-1, T (row-major, ld 64) and S' to scratch for tsqr_apply_kernel; L (unit lower) -> X, T -> Y for W_top = L T
+    double *Ui = scr + g.offUi, *Tm = scr + g.offT, *Sm = scr + g.offS;
+    tq_bar();
+#pragma unroll
+    for (int ro = 0; ro < 4; ++ro)
+#pragma unroll
+        for (int co = 0; co < 4; ++co) {
+            const int r = 4 * br + ro, c = 4 * bc + co;
+            Ui[r * TB + c] = r <= c ? ui[ro][co] : 0.0;
+            Tm[r * TB + c] = r <= c ? t[ro][co] : 0.0;
+            X[r + XS * c] = r > c ? x[ro][co] : (r == c ? 1.0 : 0.0);
+            Y[r + XS * c] = r <= c ? t[ro][co] : 0.0;
+        }
     if (tid < TB) Sm[tid] = sg[tid];
     tq_bar();
-    __syncthreads();
-    // ---- U^-1 in place in X's upper triangle (LAPACK dtrti2, column by column; wave 0, wave-synchronous), T to scratch meanwhile
-    if (tid < 64) {
-        const int r = tid;
-        for (int j = 0; j < TB; ++j) {
-            const double ujj = 1.0 / X[j + XS * j];
-            // column j of the inverse above the diagonal: -Uinv(0:j,0:j) U(0:j,j) ujj; thread r < j computes row r
-            double s = 0.0;
-            if (r < j)
-                for (int k = r; k < j; ++k) s += X[r + XS * k] * X[k + XS * j];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // all reads of column j done (one wave: lock-step)
-            __builtin_amdgcn_wave_barrier();
-            if (r < j) X[r + XS * j] = -s * ujj;
-            if (r == j) X[j + XS * j] = ujj;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-        }
-    } else {
-        for (int idx = tid - 64; idx < TB * TB; idx += 192) {
-            const int r = idx >> 6, c = idx & 63;
-            Tm[idx] = r <= c ? Y[r + XS * c] : 0.0;                       // row-major, ld 64: Tm[r * 64 + c]
-        }
-    }
-    tq_bar();
-    __syncthreads();
-    for (int idx = tid; idx < TB * TB; idx += 256) {
-        const int r = idx >> 6, c = idx & 63;
-        Ui[idx] = r <= c ? X[r + XS * c] : 0.0;                           // row-major, ld 64
-    }
     // ---- top 64 rows of V (= L: exact unit lower triangle) and of W = L T
     double *buf = g.buf + (long)ch * g.bsBuf, *Wg = g.W + (long)ch * g.bsW;
     {
         const int r4 = 4 * (tid & 15), c4 = 4 * (tid >> 4);
         double acc[4][4];
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
+        for (int xx = 0; xx < 4; ++xx)
 #pragma unroll
-            for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
-        for (int k = 0; k < r4 + 4; ++k) {                                 // L(r, k) = 0 for k > r
+            for (int y = 0; y < 4; ++y) acc[xx][y] = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < TB; ++k) {                                     // L(r, k) = 0 for k > r and T(k, c) = 0 for k > c: stored zeros
             double lv[4], tv[4];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) lv[x] = k < r4 + x ? X[(r4 + x) + XS * k] : (k == r4 + x ? 1.0 : 0.0);
+            for (int xx = 0; xx < 4; ++xx) lv[xx] = X[(r4 + xx) + XS * k];
 #pragma unroll
-            for (int y = 0; y < 4; ++y) tv[y] = k <= c4 + y ? Y[k + XS * (c4 + y)] : 0.0;
+            for (int y = 0; y < 4; ++y) tv[y] = Y[k + XS * (c4 + y)];
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
+            for (int xx = 0; xx < 4; ++xx)
 #pragma unroll
-                for (int y = 0; y < 4; ++y) acc[x][y] += lv[x] * tv[y];
+                for (int y = 0; y < 4; ++y) acc[xx][y] += lv[xx] * tv[y];
         }
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
+        for (int xx = 0; xx < 4; ++xx)
 #pragma unroll
             for (int y = 0; y < 4; ++y) {
-                const int r = r4 + x, c = c4 + y;
-                Wg[r + ld * c] = acc[x][y];
-                const double lv = r > c ? X[r + XS * c] : (r == c ? 1.0 : 0.0);
+                const int r = r4 + xx, c = c4 + y;
+                Wg[r + ld * c] = acc[xx][y];
+                const double lv = X[r + XS * c];
                 buf[r + ld * c] = lv;
                 buf[r + ld * (2 * TB + c)] = lv;
             }
@@ -422,34 +525,37 @@ __global__ __launch_bounds__(256) void tsqr_tree_kernel(TsqrArgs g)
 constexpr int BS = 66;                                                    // leading dimension of the row-major LDS matrices here
 constexpr int TQ_LDS_APPLY = 2 * TB * BS * 8;                             // 67 584 bytes
 
-// C = A B, 64 x 64, A and C row-major in LDS (ld BS), B from global or LDS through its strides
-__device__ __forceinline__ void tq_mm64r(const double *A, const double *B, long sBk, long sBn, double *C, int tid)
+// C = A B, 64 x 64, on the matrix cores: A and C row-major in LDS (ld BS), B from global memory (or LDS) through its strides, fetched
+// straight into MFMA operand registers (all 64 loads of a lane in flight before the first MFMA).  Wave w computes rows 16 w .. 16 w + 15:
+// a = A[m = lane & 15][k = lane >> 4], b = B[k = lane >> 4][n = lane & 15], acc[r] = C[m = (lane >> 4) + 4 r][n = lane & 15].
+__device__ __forceinline__ void tq_mm64m(const double *A, const double *B, long sBk, long sBn, double *C, int lane, int wave)
 {
-    const int r4 = 4 * (tid >> 4), c4 = 4 * (tid & 15);
-    double acc[4][4];
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double4_t acc[4];
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
-#pragma unroll 4
-    for (int k = 0; k < 64; ++k) {
-        double av[4], bv[4];
+    for (int h = 0; h < 2; ++h) {                    // two halves of K: 32 loads of a lane in flight at a time
+        double bf[8][4];
 #pragma unroll
-        for (int x = 0; x < 4; ++x) av[x] = A[(r4 + x) * BS + k];
+        for (int q = 0; q < 8; ++q)
 #pragma unroll
-        for (int y = 0; y < 4; ++y) bv[y] = B[k * sBk + (c4 + y) * sBn];
+            for (int nt = 0; nt < 4; ++nt) bf[q][nt] = B[(long)(4 * (8 * h + q) + l4) * sBk + (long)(16 * nt + l15) * sBn];
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
+        for (int q = 0; q < 8; ++q) {
+            const double av = A[(16 * wave + l15) * BS + 4 * (8 * h + q) + l4];
 #pragma unroll
-            for (int y = 0; y < 4; ++y) acc[x][y] += av[x] * bv[y];
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bf[q][nt], acc[nt], 0, 0, 0);
+        }
     }
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int y = 0; y < 4; ++y) C[(r4 + x) * BS + (c4 + y)] = acc[x][y];
+        for (int r = 0; r < 4; ++r) C[(16 * wave + l4 + 4 * r) * BS + 16 * nt + l15] = acc[nt][r];
 }
 
-__global__ __launch_bounds__(256) void tsqr_apply_kernel(TsqrArgs g)
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void tsqr_apply_kernel(TsqrArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) double tq_lds[];
     double *M0 = tq_lds, *M1 = M0 + TB * BS;
@@ -481,17 +587,17 @@ __global__ __launch_bounds__(256) void tsqr_apply_kernel(TsqrArgs g)
         for (int l = 2; l < pl.nlev; ++l) {
             const int k = idx & 3; idx >>= 2;
             const double *Qp = Qall + (long)(pl.base[l] + idx) * (TR * TB) + TB * k;
-            tq_mm64r(cur, Qp, 1, TR, oth, tid);
+            tq_mm64m(cur, Qp, 1, TR, oth, lane, wave);
             tq_bar();
             __syncthreads();
             double *t = cur; cur = oth; oth = t;
         }
-        tq_mm64r(cur, Ui, TB, 1, oth, tid);
+        tq_mm64m(cur, Ui, TB, 1, oth, lane, wave);
         tq_bar();
         __syncthreads();
         BV = oth; BW = cur;
     }
-    tq_mm64r(BV, Tm, TB, 1, BW, tid);
+    tq_mm64m(BV, Tm, TB, 1, BW, lane, wave);
     // meanwhile-independent: the panel itself becomes [S' R; 0]
     {
         double *P = g.A + (long)ch * g.bsA + (long)g.c0 * ld + g.r0;
@@ -605,23 +711,29 @@ int tsqr_panel(int npad, int r0, int c0, int batch, double *d_A, double *buf, do
     g.offQ = 0;
     g.offR = (long)pmax.ntot * (TR * TB);
     g.offUi = g.offR + (long)pmax.ntot * (TB * TB);
-    g.offT = g.offUi + TB * TB; g.offL = g.offT + TB * TB; g.offS = g.offL + TB * TB;
+    g.offT = g.offUi + TB * TB; g.offS = g.offT + TB * TB;
     g.cntr = cntr;
     g.bsCntr = tsqr_cntr_ints(npad);
     static bool attr = false;
     if (!attr) {
-        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tsqr_tree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TQ_LDS_TREE));
-        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tsqr_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TQ_LDS_APPLY));
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tsqr_tree_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, TQ_LDS_TREE));
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tsqr_apply_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, TQ_LDS_APPLY));
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tsqr_tree_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, TQ_LDS_TREE));
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tsqr_apply_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, TQ_LDS_APPLY));
         attr = true;
     }
     const dim3 grid(g.plan.cnt[0], batch);
     {
         KScope kt(KS_PANEL_QR, st);
-        hipLaunchKernelGGL(tsqr_tree_kernel, grid, dim3(256), TQ_LDS_TREE, st, g);
+        // tsqr_regcap = 1: the variants limited to 256 registers (they fit beside ONE rank-128-update workgroup of a CU, at the price
+        // of a few spills outside the column loops)
+        if (opts().tsqr_regcap) hipLaunchKernelGGL(tsqr_tree_kernel<2>, grid, dim3(256), TQ_LDS_TREE, st, g);
+        else hipLaunchKernelGGL(tsqr_tree_kernel<1>, grid, dim3(256), TQ_LDS_TREE, st, g);
     }
     {
         KScope kt(KS_CHAIN, st);
-        hipLaunchKernelGGL(tsqr_apply_kernel, grid, dim3(256), TQ_LDS_APPLY, st, g);
+        if (opts().tsqr_regcap) hipLaunchKernelGGL(tsqr_apply_kernel<2>, grid, dim3(256), TQ_LDS_APPLY, st, g);
+        else hipLaunchKernelGGL(tsqr_apply_kernel<1>, grid, dim3(256), TQ_LDS_APPLY, st, g);
     }
     BSP_HIP(hipGetLastError());
     return BSP_OK;

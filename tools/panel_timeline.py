@@ -29,7 +29,8 @@ for t, d in ev:
     if c == 0: idle += t - last
     c += d; last = t
 print("  GPU idle (no kernel running) inside the step: %.2f ms" % (idle / 1e6))
-qr = [i for i, r in enumerate(step) if r[2].startswith("panel_qr")]
+qr = [i for i, r in enumerate(step) if r[2].startswith("panel_qr") or r[2].startswith("tsqr_tree")]
+print("panel factorisation kernel, duration by panel (us):", " ".join("%.0f" % ((step[i][1] - step[i][0]) / 1e3) for i in qr))
 want = [int(x) for x in sys.argv[2:]] or [0, 1, 8, 24, 40, 56, 62]
 print("panels in trace: %d" % len(qr))
 for p in want:
