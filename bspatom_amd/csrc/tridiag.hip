@@ -674,15 +674,16 @@ int launch_bisect_one(int n, const double *d_d, const double *d_e, int m, double
 int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_e, double *d_w, long ldw,
                   hipStream_t st)
 {
-    // Eight eigenvalues per thread when that still fills the GPU (>= 256 workgroups): the same speed as four (measured
-    // 15.7 against 15.6 ms), but one workgroup per CU instead of two, so that half of every CU's LDS stays free
-    // for the one-wave kernels of the consumed eigenvector that run beside this one.
-    // 2048 eigenvalues per workgroup: four per thread on 512 threads when that still fills the GPU (>= 256 workgroups),
-    // else 1024 per workgroup (four per thread on 256 threads).  BSP_BISECT_EPT = 8: eight per thread on 256 threads
-    // (round 1's choice), 4: four per thread on 256 threads.
+    // ONE workgroup shape for every batch size: 512 threads x 2 eigenvalues = 1024 evaluation slots and 1024 eigenvalues per
+    // workgroup.  The bracket sequence of an eigenvalue depends on the first-level grid (its size = the slots) and on which
+    // eigenvalues share a multisection tail, so a shape chosen by batch size (rounds 1-2: 512 x 4 for >= 256 workgroups, else
+    // 256 x 4) made the last bits of a spectrum depend on how many channels were solved together.  Measured (round 3, n = 4096):
+    // 128 channels 23.3 ms against 23.0 with 512 x 4; 32 channels 12.1 against 13.0; 16 channels 11.3 against 12.3 (256 x 2,
+    // BSP_BISECT_EPT=21: 26.2 / 8.5 / 7.8 ms -- faster for small batches, 3 ms slower for the full one).
+    // BSP_BISECT_EPT: 8 = 256 x 8 (round 1), 4 = 256 x 4, 2 = 1024 x 2, 21 = 256 x 2, 5 = 512 x 4.
     const int ept_env = opts().bisect_ept;
-    int mode = (ept_env == 8) ? 8 : (ept_env == 4) ? 4 : (ept_env == 2) ? 1024 : ((((n + 2047) / 2048) * batch >= 256) ? 512 : 4);
-    int ng = (mode == 4) ? 1024 : 2048;
+    int mode = (ept_env == 8) ? 8 : (ept_env == 4) ? 4 : (ept_env == 2) ? 1024 : (ept_env == 21) ? 21 : (ept_env == 5) ? 512 : 22;
+    int ng = (mode == 4) ? 1024 : (mode == 21 ? 512 : (mode == 22 ? 1024 : 2048));
     if (bisect3_lds_bytes(n, ng) > 150 * 1024) { mode = 4; ng = 1024; }          // n = 8192: 146 KB with 1024 slots
     const size_t lds3 = bisect3_lds_bytes(n, ng);
     const size_t lds = (size_t)2 * (n + 3 * RS + HW) * sizeof(double);    // variants 1 and 2
@@ -702,6 +703,10 @@ int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect3_kernel<2, 1024>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect3_kernel<2, 256>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bisect3_kernel<2, 512>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
     const dim3 grid((n + 256 * EPT - 1) / (256 * EPT), batch);
@@ -714,6 +719,8 @@ int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_
         if (mode == 512) hipLaunchKernelGGL((bisect3_kernel<4, 512>), g3, dim3(512), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
         else if (mode == 1024) hipLaunchKernelGGL((bisect3_kernel<2, 1024>), g3, dim3(1024), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
         else if (mode == 8) hipLaunchKernelGGL((bisect3_kernel<8, 256>), g3, dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
+        else if (mode == 21) hipLaunchKernelGGL((bisect3_kernel<2, 256>), g3, dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
+        else if (mode == 22) hipLaunchKernelGGL((bisect3_kernel<2, 512>), g3, dim3(512), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
         else hipLaunchKernelGGL((bisect3_kernel<4, 256>), g3, dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
     }
     BSP_HIP(hipGetLastError());

@@ -280,6 +280,26 @@ def test_full_size_properties_128_channels():
     prob.close()
 
 
+def test_spectra_do_not_depend_on_the_batch_size():
+    """BASELINE configs[3] on N GPUs gives every GPU 128 / N channels: the spectrum of a channel must not depend on how many
+    channels are solved with it.  l = 0 .. 15 solved as a batch of 16 (what each of 8 GPUs sees), of 32, and as part of the
+    full batch of 128: bit-identical.  Everything that is chosen by batch size keeps the arithmetic: channel groups and update
+    slices of sy2sb, the rings of the bulge chasing; the panel factorisation is chosen by the panel's row count alone and the
+    bisection has one workgroup shape (rounds 1-2 picked it by batch size, which changed the last bits)."""
+    prob = capi.Problem(input_from_case("c4_4096", l_fin=127))
+    E128, info = prob.solve(0, 128)
+    assert np.all(info == 0)
+    for nb in (16, 32, 1):
+        Eb, info = prob.solve(0, nb)
+        assert np.all(info == 0)
+        assert np.array_equal(Eb, E128[:nb]), "batch of %d differs from the batch of 128 (max rel %.1e)" % (
+            nb, np.max(np.abs(Eb - E128[:nb]) / np.abs(E128[:nb])))
+    # a block that does not start at l = 0 (rank r of N owns l = r * 128 / N ..)
+    Eb, info = prob.solve(48, 16)
+    assert np.array_equal(Eb, E128[48:64])
+    prob.close()
+
+
 def test_full_size_batch_is_deterministic():
     """The paired bulge-chasing workgroups synchronise through published progress words; the arithmetic and its
     order do not depend on their timing, so repeated solves must agree bit for bit (a race shows up as a difference)."""
