@@ -10,6 +10,8 @@
 #   oracle/_ref/ref_dump.x      ref_dump_driver.f90 + the same reference objects (PhotoIon.f90 with one
 #                               diagnostic WRITE shortened, see below); also writes ref_dump.bin
 #                               (module state) for the golden fixtures.
+#   oracle/_ref/ref_handoff.x   ref_handoff_driver.f90 + the reference objects: the reference's READ_COUP (ReadInputs.f90:277-369)
+#                               reads Enl.dat / CSs/MatElem_All.dat the PRODUCT wrote; its WRITE forms for MatElem_All.dat.
 #   oracle/_ref/Bsp_Atom_gpu.x  THE SAME reference objects as Bsp_Atom_ref.x, linked with -lbspatom_lapack in front of
 #                               the CPU LAPACK: `dsygv_` (matrices.f90:248) resolves to the GPU library, every
 #                               other BLAS symbol still to OpenBLAS -- the link-level drop-in of INTEGRATION.md 1,
@@ -55,6 +57,9 @@ COMMON="Modules.o ReadInputs.o matrices.o PhotoIon.o WriteWF.o grid.o CubicSplin
 LINK="$OPENBLAS -Wl,-rpath,$SCIPY_LIBS -lm"
 "$FC" -o "$OUT/Bsp_Atom_ref.x" Bsp_Atom.o $COMMON $LINK
 "$FC" -o "$OUT/ref_dump.x" ref_dump_driver.o Bsp_Atom_subs.o ${COMMON/PhotoIon.o/PhotoIon_dump.o} $LINK
+# hand-off formats: the reference's own reader READ_COUP on files the product wrote, see the driver's header
+"$FC" $FFLAGS -c "$HERE/ref_handoff_driver.f90" -o ref_handoff_driver.o
+"$FC" -o "$OUT/ref_handoff.x" ref_handoff_driver.o Bsp_Atom_subs.o $COMMON $LINK
 # link-level drop-in: the reference's own objects against libbspatom_lapack.so (dsygv_ -> GPU).  The forwarder object
 # is compiled WITHOUT its dsygv_ (-DNO_DSYGV) so that the only definition of that symbol is the GPU library's.
 PROD=$(cd "$HERE/../../bspatom_amd" && pwd)

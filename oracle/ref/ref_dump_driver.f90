@@ -11,7 +11,8 @@
       USE MOD_MATRICES
       USE MOD_PHOTOION
       IMPLICIT NONE
-      INTEGER :: c0, c1, c2, crate
+      INTEGER :: c0, c1, c2, crate, envlen
+      CHARACTER(LEN=8) :: envbuf
       CALL READ_INPUTS
       CALL GRID
       CALL SEL_LM
@@ -71,6 +72,15 @@
         WRITE(93) Enl(1:nfun,0:lmax)
         WRITE(93) rEki(1:nfun,0:lmax)
         CLOSE(93)
+      END IF
+!     KIND_PI >= 3, on request (REF_DUMP_TRANS_AMP_PI3 set): the reference's own TRANS_AMP as far as it runs in this container.
+!     Its Gaussian / LG-beam branch needs MAKE_F_ANG (Ang_Ints.f90), which aborts with a heap corruption under flang -O2
+!     (Bsp_Atom.f90:66 is not called here); without it ncomp = nket = 0 and TRANS_AMP writes the header of
+!     CSs/MatElem_All.dat (PhotoIon.f90:255-256) and no record -- that header is what the hand-off fixture keeps of it.
+      CALL GET_ENVIRONMENT_VARIABLE('REF_DUMP_TRANS_AMP_PI3', envbuf, envlen)
+      IF( KIND_PI >= 3 .AND. envlen > 0 ) THEN
+        CALL EXECUTE_COMMAND_LINE('mkdir -p CSs')
+        CALL TRANS_AMP
       END IF
       WRITE(6,'(A,F12.4)') 'REF_TIME_MATRIX_SVT_S ', DBLE(c1-c0)/DBLE(crate)
       WRITE(6,'(A,F12.4)') 'REF_TIME_SOLVE_SYSTEM_S ', DBLE(c2-c1)/DBLE(crate)

@@ -331,7 +331,78 @@ def run_spectra(name, text):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print("%-14s nfun=%5d channels=%3d  E1=%.15g  wall %.0f s" % (name, nfun, E.shape[0], E[0, 0], wall), flush=True)
 
+def run_handoff():
+    """the hand-off files.  (1) Enl.dat and CSs/MatElem_All.dat written by the PRODUCT's writers
+    (bspatom_amd/host.py) are read by the REFERENCE'S OWN reader READ_COUP (ReadInputs.f90:277-369, unmodified, through
+    oracle/ref/ref_handoff_driver.f90); what it read goes into the fixture next to the file texts.  (2) The same couplings
+    written with the reference's two WRITE forms for MatElem_All.dat (PhotoIon.f90:255-266) by this Fortran runtime.  (3) The
+    MatElem_All.dat the reference's own TRANS_AMP writes for KIND_PI = 3 in this container (header only: see the driver)."""
+    sys.path.insert(0, ROOT)
+    from bspatom_amd import host
+    hx = os.path.join(ROOT, "oracle", "_ref", "ref_handoff.x")
+    if not os.path.exists(hx):
+        sys.exit("oracle/_ref/ref_handoff.x missing: run oracle/ref/build_ref.sh first")
+    rng = np.random.default_rng(20261004)
+    out = {}
+    for kind_pi, nfields in ((3, 1), (5, 2), (8, 5)):
+        lmax, nfun, n1_max = 1, 9, 3
+        E = np.sort(rng.standard_normal((lmax + 1, nfun)) * 10.0 ** rng.integers(-9, 4, size=(lmax + 1, nfun)), axis=1)
+        E[:, 0] = -0.5 / np.arange(1, lmax + 2) ** 2
+        nbra = nket = n1_max * 2
+        zT = (rng.standard_normal((nbra, nket, nfields)) + 1j * rng.standard_normal((nbra, nket, nfields))) * \
+            10.0 ** rng.integers(-12, 6, size=(nbra, nket, nfields))
+        zT[0, 1, 0] = 0.0
+        zT[1, 2, 0] = 1.0 - 0.1j
+        emax_fin = 0.25
+        with tempfile.TemporaryDirectory(prefix="bspgold.") as tmp:
+            rr = np.linspace(0.0, 1.0, 3)
+            host.write_structure_outputs(nfun, lmax, E, 0, (rr, rr), tmp)
+            host.write_matelem_all(os.path.join(tmp, "CSs", "MatElem_All.dat"), n1_max, zT)
+            enl_text = open(os.path.join(tmp, "Enl.dat")).read()
+            me_text = open(os.path.join(tmp, "CSs", "MatElem_All.dat")).read()
+            ctl = "'R'\n%d %d %.17g %d %d %d\n" % (lmax, kind_pi, emax_fin, 1, 0, 0)
+            p = subprocess.run([hx], input=ctl, cwd=tmp, capture_output=True, text=True)
+            if p.returncode != 0 or "Error" in p.stdout:
+                sys.exit("READ_COUP failed on the product's files: %s %s" % (p.stdout[-500:], p.stderr[-500:]))
+            raw = open(os.path.join(tmp, "ref_handoff.bin"), "rb").read()
+            hdr = np.frombuffer(raw, dtype=np.int32, count=6); off = 24
+            rnfun, rn1, rnbra, rnket, rnf, rlmax = (int(x) for x in hdr)
+            rE = np.frombuffer(raw, dtype=np.float64, count=rnfun * (rlmax + 1), offset=off).reshape(rlmax + 1, rnfun); off += 8 * rE.size
+            rn01 = np.frombuffer(raw, dtype=np.int32, count=3 * (rlmax + 1), offset=off).reshape(3, rlmax + 1).T; off += 4 * rn01.size
+            rz = np.frombuffer(raw, dtype=np.complex128, count=rnbra * rnket * rnf, offset=off).reshape(rnf, rnket, rnbra).transpose(2, 1, 0)
+            # (2) the reference's WRITE forms through this Fortran runtime
+            vals = "".join("%.17g %.17g\n" % (zT[ib, jk, i].real, zT[ib, jk, i].imag) for ib in range(nbra) for jk in range(ib, nket)
+                           for i in range(nfields))
+            p2 = subprocess.run([hx], input="'W'\n%d %d %d %d\n%s" % (n1_max, nbra, nket, nfields, vals), cwd=tmp, capture_output=True, text=True)
+            if p2.returncode != 0:
+                sys.exit("format driver failed: " + p2.stderr[-500:])
+            me_fortran = open(os.path.join(tmp, "MatElem_All.dat")).read()
+        tag = "pi%d_" % kind_pi
+        out.update({tag + "E": E, tag + "zT": zT, tag + "emax_fin": emax_fin, tag + "n1_max": n1_max, tag + "nfields": nfields,
+                    tag + "enl_text": np.array(enl_text), tag + "matelem_text": np.array(me_text),
+                    tag + "matelem_text_fortran": np.array(me_fortran),
+                    tag + "read_header": np.array([rnfun, rn1, rnbra, rnket, rnf, rlmax]), tag + "read_E": rE, tag + "read_n01": rn01,
+                    tag + "read_z": rz})
+        print("handoff KIND_PI=%d: READ_COUP read nfun=%d n1_max=%d nbra=%d nket=%d nfields=%d; max|dE| %.1e max|dz| rel %.1e; "
+              "Fortran-written MatElem_All.dat %s the product's" % (kind_pi, rnfun, rn1, rnbra, rnket, rnf, np.max(np.abs(rE - E)),
+              np.max(np.abs(np.triu(rz[:, :, 0] - zT[:, :, 0])) / np.max(np.abs(zT))), "==" if me_fortran == me_text else "!="))
+    # (3) the reference's TRANS_AMP for KIND_PI = 3 as far as it runs here: header of its MatElem_All.dat
+    with tempfile.TemporaryDirectory(prefix="bspgold.") as tmp:
+        text = PI3["pi3_emax1"]
+        os.makedirs(os.path.join(tmp, "CSs"))
+        p = subprocess.run([REFX], input=text + "\n", cwd=tmp, capture_output=True, text=True, env=dict(os.environ, REF_DUMP_TRANS_AMP_PI3="1"))
+        f = os.path.join(tmp, "CSs", "MatElem_All.dat")
+        out["ref_pi3_matelem_text"] = np.array(open(f).read() if os.path.exists(f) else "")
+        print("reference TRANS_AMP (KIND_PI = 3, MAKE_F_ANG not callable here) wrote MatElem_All.dat: %r" % str(out["ref_pi3_matelem_text"]))
+    out["source"] = np.array("tests/golden/make_golden.py --handoff: oracle/_ref/ref_handoff.x (the reference's READ_COUP on the product's files; "
+                             "the reference's WRITE forms through flang's runtime); oracle/_ref/ref_dump.x for the KIND_PI = 3 header")
+    np.savez_compressed(os.path.join(HERE, "handoff.npz"), **out)
+
+
 def main():
+    if "--handoff" in sys.argv[1:]:
+        run_handoff()
+        return
     if not os.path.exists(REFX):
         sys.exit("oracle/_ref/ref_dump.x missing: run oracle/ref/build_ref.sh first")
     args = sys.argv[1:]

@@ -450,6 +450,53 @@ def test_committed_bench_line_keeps_the_contract():
     assert "value_scaled_to_nfun4096" not in c                       # measured at the metric's size, not extrapolated
 
 
+@pytest.mark.parametrize("kind_pi", [3, 5, 8])
+def test_handoff_files_against_the_reference_reader(tmp_path, kind_pi):
+    """SURVEY 8(f).3, pinned from the CONSUMER's side (tests/golden/handoff.npz, make_golden.py --handoff): Enl.dat and
+    CSs/MatElem_All.dat as this repo's writers produce them were read by the reference's own READ_COUP (ReadInputs.f90:277-369,
+    unmodified, oracle/ref/ref_handoff_driver.f90) for nfields = 1, 2, 5 (KIND_PI = 3, 5, 8).  Here: (a) today's writers still
+    produce exactly the texts that reader consumed; (b) what it read equals what was written, to the files' digits (G22.15,
+    G20.10), including the (1, n1_fin, n0_fin) limits it rebuilds from Enl.dat and which components it keeps (the first one; all
+    five only for KIND_PI >= 8, :351-358); (c) this repo's readers return the same; (d) MatElem_All.dat written with the
+    reference's two WRITE forms (PhotoIon.f90:255-266: list-directed header, FORMAT(2I8,X,20G20.10)) by the Fortran runtime is
+    byte-identical to the Python writer's; (e) the one MatElem_All.dat the reference's own TRANS_AMP can write in the build
+    container (KIND_PI = 3 without the angular integrals, which abort there: header only) is read by read_matelem_all."""
+    from bspatom_amd import host
+    g = load_golden("handoff")
+    t = "pi%d_" % kind_pi
+    E, zT, emax, n1_max, nf = g[t + "E"], g[t + "zT"], float(g[t + "emax_fin"]), int(g[t + "n1_max"]), int(g[t + "nfields"])
+    lmax, nfun = E.shape[0] - 1, E.shape[1]
+    rr = np.linspace(0.0, 1.0, 3)
+    host.write_structure_outputs(nfun, lmax, E, 0, (rr, rr), str(tmp_path))
+    me = tmp_path / "CSs" / "MatElem_All.dat"
+    host.write_matelem_all(str(me), n1_max, zT)
+    assert open(tmp_path / "Enl.dat").read() == str(g[t + "enl_text"])                          # (a)
+    assert open(me).read() == str(g[t + "matelem_text"])
+    assert str(g[t + "matelem_text_fortran"]) == str(g[t + "matelem_text"])                    # (d)
+    rnfun, rn1, rnbra, rnket, rnf, rlmax = (int(x) for x in g[t + "read_header"])             # (b)
+    assert (rnfun, rn1, rnbra, rnket, rnf, rlmax) == (nfun, n1_max, zT.shape[0], zT.shape[1], nf, lmax)
+    assert np.max(np.abs(g[t + "read_E"] - E) / np.abs(E)) < 1e-14
+    rz = g[t + "read_z"]
+    keep = nf if kind_pi >= 8 else 1
+    iu = np.triu_indices(zT.shape[0])
+    for c in range(nf):
+        want = zT[:, :, c][iu] if c < keep else np.zeros(len(iu[0]))
+        scale = np.maximum(np.abs(zT[:, :, c][iu]), 1e-300)
+        assert np.max(np.abs(rz[:, :, c][iu] - want) / scale) < 1e-9
+    assert np.all(rz[np.tril_indices(zT.shape[0], -1)] == 0)                                    # records cover jket >= ibra only
+    n_, E2, n01 = host.read_enl(str(tmp_path / "Enl.dat"), lmax, emax)                         # (c)
+    assert n_ == nfun and np.array_equal(E2, g[t + "read_E"]) and np.array_equal(n01, g[t + "read_n01"])
+    n1r, z2 = host.read_matelem_all(str(me), nfields=nf)
+    assert n1r == n1_max
+    for c in range(keep):
+        assert np.array_equal(z2[:, :, c][iu], rz[:, :, c][iu])
+    hdr = tmp_path / "ref_header_only.dat"                                                      # (e)
+    hdr.write_text(str(g["ref_pi3_matelem_text"]))
+    assert str(g["ref_pi3_matelem_text"]) == " 44 396 0\n"
+    n1h, zh = host.read_matelem_all(str(hdr), nfields=1)
+    assert n1h == 44 and zh.shape == (396, 0, 1)
+
+
 def test_matelem_all_round_trip(tmp_path):
     """CSs/MatElem_All.dat (PhotoIon.f90:255-266 writer, ReadInputs.f90:324-366 reader): header `n1_max nbra nket`, records
     FORMAT(2I8,X,20G20.10) for jket >= ibra; READ_COUP reads them list-directed, 2 nfields reals per record."""
