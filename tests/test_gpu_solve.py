@@ -685,6 +685,43 @@ def test_bsp_dsygv_all_vectors_at_2048():
     assert np.max(np.abs(np.triu(U).T @ np.triu(U) - Sf)) < 1e-12
 
 
+def test_bsp_dsygv_all_vectors_at_4096_timed():
+    """The full DSYGV(1,'V','U') contract at the size of BASELINE configs[3] (matrices.f90:248; n = 4096, the reference's
+    SOLVE_SYSTEM takes 44 s per channel for it on 16 host cores): all 4096 S-orthonormal eigenvectors through the LAPACK-symbol
+    boundary, TIMED (wall time of the call, host buffers in and out: two dense 134 MB matrices; noted in
+    gpurun_out/stage_metrics.txt and copied to profiles/).  The eigenvalue clusters of this pencil (neighbours closer than
+    1e-5 lambda_max, chained) reach 1001 members: round 2's host-side Gram-Schmidt was O(m^2 n k) there (advisor finding); the
+    blocked S-orthonormalisation now runs on the GPU (csrc/dsygv.hip)."""
+    import time
+    import oracle as orc
+    from tests_truth import case_cfg
+    c = case_cfg("c4_4096")
+    rt, aind, xg, wg = orc.grid(c)
+    SB, HB = orc.assemble_bands(c, rt, aind, xg, wg, 0, 1)
+    S = orc.band_to_dense_upper(SB); H = orc.band_to_dense_upper(HB[0])
+    capi.dsygv(H[:64, :64].copy(), S[:64, :64].copy(), jobz="N")          # first call of the process: code objects, streams
+    t0 = time.perf_counter()
+    wN, _, _, infoN = capi.dsygv(H, S, jobz="N", uplo="U")
+    tN = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    w, Z, U, info = capi.dsygv(H, S, jobz="V", uplo="U")
+    tV = time.perf_counter() - t0
+    assert info == 0 and infoN == 0 and np.array_equal(w, wN)
+    g = load_golden("c4_4096")
+    full_size_bar(w, g["E"][0], "bsp_dsygv_('V') c4_4096", load_truth("c4_4096")[0])
+    Sf = S + np.triu(S, 1).T; Hf = H + np.triu(H, 1).T
+    SZ = Sf @ Z
+    orth = np.max(np.abs(Z.T @ SZ - np.eye(c.nfun)))
+    resid = np.max(np.abs(Hf @ Z - SZ * w)) / np.max(np.abs(w))
+    lam = np.max(np.abs(w)); gaps = np.diff(w) <= 1e-5 * lam
+    runs = np.diff(np.flatnonzero(np.diff(np.concatenate([[0], gaps.astype(int), [0]]))))[::2] + 1 if gaps.any() else np.array([1])
+    note("bsp_dsygv_ n=4096 one channel through the dsygv_ symbol boundary (host matrices in, host results out): JOBZ='N' %.2f s, "
+         "JOBZ='V' (all 4096 vectors) %.2f s; largest eigenvalue cluster %d; Z^T S Z - I %.2e  residual/lambda_max %.2e"
+         % (tN, tV, int(runs.max()), orth, resid))
+    assert orth <= 1e-8 and resid <= 1e-11
+    assert tV < 30.0          # the reference's DSYGV('V') on 16 host cores: 44 s (bench.py cpu_baseline, same box)
+
+
 def test_bsp_dsygv_argument_checks():
     """LAPACK's argument numbering: LWORK too small -> -11; the query returns 3n-1."""
     import ctypes as C
