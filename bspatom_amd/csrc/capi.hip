@@ -7,6 +7,7 @@
 #include <vector>
 #include "common.h"
 #include "host_setup.h"
+#include "../../include/bspatom.h"
 
 using namespace bsp;
 
@@ -175,7 +176,11 @@ extern "C" int bspatom_host_setup(const bspatom_input *in, bspatom_sizes *s, dou
 {
     if (!in || !s) return BSP_ERR_ARG;
     HostSetup h;
-    if (derive(*in, &h) != 0) return BSP_ERR_ARG;
+    {
+        const int drc = derive(*in, &h);
+        if (drc == -5) { fprintf(stderr, "bspatom: k = %d / ka = %d exceed this build's limits k <= %d, ka <= %d\n", in->k, h.ka, BSPATOM_MAX_K, BSPATOM_MAX_KA); return BSP_ERR_UNSUPPORTED; }
+        if (drc != 0) return BSP_ERR_ARG;
+    }
     s->nfun = h.nfun; s->k = h.k; s->ka = h.ka; s->nkp = h.nkp; s->nointv = h.nointv;
     s->nbc1 = h.nbc1; s->nbc2 = h.nbc2; s->lmax = h.lmax; s->nintv_exp = h.nintv_exp;
     s->nintv_lin = h.nintv_lin; s->npad = round_up(h.nfun, 64);
@@ -224,9 +229,22 @@ static int upload(T **dst, const T *src, size_t count)
 
 static int problem_init(bspatom_problem *p, const bspatom_input *in, int device)
 {
-    if (derive(*in, &p->hs) != 0) return BSP_ERR_ARG;
-    if (p->hs.nfun > 8256) {          // the dense -> band stage holds a panel in one workgroup (sy2sb.hip), the bisection the
-        fprintf(stderr, "bspatom: nfun = %d exceeds the 8256 functions per channel this build supports\n", p->hs.nfun);   // matrix in LDS
+    {
+        const int drc = derive(*in, &p->hs);
+        if (drc == -5) {
+            fprintf(stderr, "bspatom: B-spline order k = %d (Gauss-Legendre points ka = %d) exceeds the limits k <= %d, ka <= %d of this build\n",
+                    in->k, p->hs.ka, BSPATOM_MAX_K, BSPATOM_MAX_KA);
+            return BSP_ERR_UNSUPPORTED;
+        }
+        if (drc != 0) return BSP_ERR_ARG;
+    }
+    if (p->hs.nfun > BSPATOM_MAX_NFUN) {       // the reference's own limit is nfun <= 9999 (its Enl.dat record is I4, matrices.f90:391)
+        fprintf(stderr, "bspatom: nfun = %d exceeds the %d functions per channel this build supports\n", p->hs.nfun, BSPATOM_MAX_NFUN);
+        return BSP_ERR_UNSUPPORTED;
+    }
+    if (p->hs.k > BSPATOM_MAX_K || p->hs.ka > BSPATOM_MAX_KA) {
+        fprintf(stderr, "bspatom: B-spline order k = %d (Gauss-Legendre points ka = %d) exceeds the limits k <= %d, ka <= %d of this build\n",
+                p->hs.k, p->hs.ka, BSPATOM_MAX_K, BSPATOM_MAX_KA);
         return BSP_ERR_UNSUPPORTED;
     }
     build_grid(&p->hs);
@@ -466,13 +484,17 @@ static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, dou
         // chasing, eigenvector at +30 ms.
         BSP_HIP(hipMemcpyAsync(p->d_chan, &p->pre_ch, sizeof(int), hipMemcpyHostToDevice, p->st));
         BSP_HIP(hipMemsetAsync(p->d_pinfo, 0, sizeof(int), p->st));
-        if ((rc = launch_bisect_one(n, p->d_d + (size_t)ch * np, p->d_e + (size_t)ch * np, tn0 - 1, p->d_pE, p->st))) return rc;
-        BSP_HIP(hipEventRecord(p->evx, p->st));
-        BSP_HIP(hipStreamWaitEvent(p->st2, p->evx, 0));
-        if ((rc = launch_inverse_iteration(n, h.k, 1, p->d_SB, p->d_HB, p->d_chan, p->d_pE, p->d_vwork, p->d_pvec,
-                                           p->d_pinfo, p->st2))) return rc;
-        BSP_HIP(hipEventRecord(p->evx, p->st2));
-        p->pre_l = tl; p->pre_n0 = tn0;
+        rc = launch_bisect_one(n, p->d_d + (size_t)ch * np, p->d_e + (size_t)ch * np, tn0 - 1, p->d_pE, p->st);
+        if (rc == BSP_ERR_UNSUPPORTED) rc = BSP_OK;          // the one-workgroup kernel holds the matrix in LDS (n <= ~9000): beyond
+        else if (rc) return rc;                              // that bspatom_eigvec computes the vector on demand from the spectra
+        else {
+            BSP_HIP(hipEventRecord(p->evx, p->st));
+            BSP_HIP(hipStreamWaitEvent(p->st2, p->evx, 0));
+            if ((rc = launch_inverse_iteration(n, h.k, 1, p->d_SB, p->d_HB, p->d_chan, p->d_pE, p->d_vwork, p->d_pvec,
+                                               p->d_pinfo, p->st2))) return rc;
+            BSP_HIP(hipEventRecord(p->evx, p->st2));
+            p->pre_l = tl; p->pre_n0 = tn0;
+        }
     }
     if ((rc = launch_bisect(n, np, nl, p->d_d, p->d_e, Eout, n, p->st))) return rc;
     BSP_HIP(hipEventRecord(p->ev[5], p->st));

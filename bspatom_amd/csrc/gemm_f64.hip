@@ -643,7 +643,7 @@ int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const doub
     int T = 0;
     g.yoff = (part == 2) ? 1 : 0;
     const int nsx = (nb + 7) / 8;
-    if (nsx * (nsx + 1) / 2 + nsx > 56) return BSP_ERR_UNSUPPORTED;
+    if (nsx * (nsx + 1) / 2 + nsx > 80) return BSP_ERR_UNSUPPORTED;   // m <= 11264
     g.nsb = 0;
     for (int sx = 0; sx < nsx; ++sx)
         for (int sy = 0; sy <= ((sx + 1 < nsx - 1) ? sx + 1 : nsx - 1); ++sy) {

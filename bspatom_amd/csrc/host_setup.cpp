@@ -42,7 +42,8 @@ int derive(const bspatom_input &in, HostSetup *h)
     }
     h->nfun = nfun; h->k = k; h->nkp = nkp; h->nointv = nointv;
     h->lmax = (in.l_fin > in.lmax) ? in.l_fin : in.lmax;
-    if (k < 2 || k > 16 || nfun < k || h->ka < 1 || h->ka > 32 || nointv < 1) return -2;
+    if (k < 2 || nfun < k || h->ka < 1 || nointv < 1) return -2;
+    if (k > 16 || h->ka > 32) return -5;                      // BSPATOM_MAX_K / BSPATOM_MAX_KA (include/bspatom.h): device tables
     if (in.kind_grid < 0 || in.kind_grid > 2 || in.kind_pot < 0 || in.kind_pot > 2) return -2;
     if (in.kind_grid == 2 && (h->nintv_exp < 2 || h->nintv_lin < 1)) return -2;
     if (in.kind_grid == 1 && nointv < 2) return -2;

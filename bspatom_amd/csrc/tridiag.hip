@@ -265,8 +265,43 @@ __global__ __launch_bounds__(256) void bisect2_kernel(int n, int ldn, const doub
 //     only on its own bracket and on K, so the spectra stay bit-identical from run to run.
 constexpr int HW = 32;     // rows per sign-history word (np is padded to a multiple of it)
 
+// Rows 1 .. nl come from LDS (de), rows nl + 1 .. np from global memory (gt, same indexing; nl = np: no global part).  The
+// global part exists for matrices whose rows do not fit the LDS (n > 8672 with 1024 slots): the loads do not depend on the
+// recurrence, so the compiler issues a block's worth ahead of their use.
+#define STURM_BLOCK(LOADROW)                                                                          \
+    {                                                                                                 \
+        _Pragma("unroll") for (int sb = 0; sb < HW / RS; ++sb) {                                      \
+            _Pragma("unroll") for (int r = 0; r < RS; ++r) {                                          \
+                const double2 v = LOADROW(ib + sb * RS + r + 1);                                      \
+                _Pragma("unroll") for (int c = 0; c < EPT; ++c) {                                     \
+                    const double pn = __builtin_fma(v.x - x[c], p1[c], -(v.y * p0[c]));               \
+                    h[c] = __builtin_amdgcn_alignbit(h[c], (unsigned)__double2hiint(pn), 31);         \
+                    p0[c] = p1[c];                                                                    \
+                    p1[c] = pn;                                                                       \
+                }                                                                                     \
+            }                                                                                         \
+            _Pragma("unroll") for (int c = 0; c < EPT; ++c) {                                         \
+                const int ea = __builtin_amdgcn_frexp_exp(p1[c]), eb = __builtin_amdgcn_frexp_exp(p0[c]); \
+                const int ex = -max(ea, eb);                                                          \
+                p1[c] = __builtin_amdgcn_ldexp(p1[c], ex);                                            \
+                p0[c] = __builtin_amdgcn_ldexp(p0[c], ex);                                            \
+            }                                                                                         \
+        }                                                                                             \
+        _Pragma("unroll") for (int c = 0; c < EPT; ++c) {                                             \
+            const unsigned t = __builtin_amdgcn_alignbit(hp[c], h[c], 1);                             \
+            cnt[c] += __builtin_popcount(h[c] ^ t);                                                   \
+            hp[c] = h[c];                                                                             \
+        }                                                                                             \
+    }
+__device__ __forceinline__ double2 sturm_gload(const double2 *p)
+{
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p));      // served by the L2: the rows were written by this kernel
+    return make_double2(v.x, v.y);
+}
 template <int EPT>
-__device__ __forceinline__ void sturm_counts3(const double2 *__restrict__ de, int np, const double (&x)[EPT], int (&cnt)[EPT])
+__device__ __forceinline__ void sturm_counts3(const double2 *__restrict__ de, int np, const double (&x)[EPT], int (&cnt)[EPT],
+                                              const double2 *__restrict__ gt = nullptr, int nl = 0x7fffffff)
 {
     double p0[EPT], p1[EPT];
     unsigned h[EPT], hp[EPT];
@@ -277,35 +312,13 @@ __device__ __forceinline__ void sturm_counts3(const double2 *__restrict__ de, in
         hp[c] = (unsigned)__double2hiint(p1[c]) >> 31;      // p_0 = 1 > 0: a negative p_1 is the first sign change
         cnt[c] = (int)hp[c]; h[c] = 0u;
     }
-    for (int ib = 0; ib < np; ib += HW) {
-#pragma unroll
-        for (int sb = 0; sb < HW / RS; ++sb) {
-#pragma unroll
-            for (int r = 0; r < RS; ++r) {
-                const double2 v = de[ib + sb * RS + r + 1];  // rows 1 .. np
-#pragma unroll
-                for (int c = 0; c < EPT; ++c) {
-                    const double pn = __builtin_fma(v.x - x[c], p1[c], -(v.y * p0[c]));
-                    h[c] = __builtin_amdgcn_alignbit(h[c], (unsigned)__double2hiint(pn), 31);
-                    p0[c] = p1[c];
-                    p1[c] = pn;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < EPT; ++c) {
-                const int ea = __builtin_amdgcn_frexp_exp(p1[c]), eb = __builtin_amdgcn_frexp_exp(p0[c]);
-                const int ex = -max(ea, eb);
-                p1[c] = __builtin_amdgcn_ldexp(p1[c], ex);
-                p0[c] = __builtin_amdgcn_ldexp(p0[c], ex);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < EPT; ++c) {
-            const unsigned t = __builtin_amdgcn_alignbit(hp[c], h[c], 1);
-            cnt[c] += __builtin_popcount(h[c] ^ t);
-            hp[c] = h[c];
-        }
-    }
+    const int nlds = nl < np ? nl : np;
+#define STURM_LDS(i) de[i]
+#define STURM_GLB(i) sturm_gload(gt + (i))
+    for (int ib = 0; ib < nlds; ib += HW) STURM_BLOCK(STURM_LDS)
+    for (int ib = nlds; ib < np; ib += HW) STURM_BLOCK(STURM_GLB)
+#undef STURM_LDS
+#undef STURM_GLB
 }
 
 // point q (0-based) of P interior points of the bracket [a, a + w]; the evaluating and the deciding thread must get
@@ -332,15 +345,17 @@ static size_t bisect3_lds_bytes(int n, int ng)
 // only ~60 % of the fp64 vector rate: tools/microbench/mfma_f64_peak, v_fma_f64 line)
 template <int EPT, int TPB>
 __global__ __launch_bounds__(TPB) void bisect3_kernel(int n, int ldn, const double *__restrict__ dall,
-                                                     const double *__restrict__ eall, double *wall, long ldw, int tail)
+                                                     const double *__restrict__ eall, double *wall, long ldw, int tail,
+                                                     double2 *gtail, int nl)
 {
     extern __shared__ double2 sde[];
     constexpr int NG = TPB * EPT;
     constexpr int NW = TPB / 64;
     constexpr int KC = NG / 2;                         // capacity of the tail list
     const int np = (n + HW - 1) / HW * HW;
-    double2 *de = sde;                                 // de[i] = (d_i, e_{i-1}^2), i = 0 .. np
-    double *llo = (double *)(sde + np + 1);            // tail list: brackets and eigenvalue numbers
+    const int nlr = nl < np ? nl : np;                 // rows 0 .. nlr live in LDS, rows nlr + 1 .. np in global memory (gtail)
+    double2 *de = sde;                                 // de[i] = (d_i, e_{i-1}^2), i = 0 .. nlr
+    double *llo = (double *)(sde + nlr + 1);           // tail list: brackets and eigenvalue numbers
     double *lhi = llo + KC;
     int *cg = (int *)(lhi + KC);                       // counts at the NG evaluation slots
     int *lm = cg + NG;
@@ -350,6 +365,8 @@ __global__ __launch_bounds__(TPB) void bisect3_kernel(int n, int ldn, const doub
     const size_t ch = blockIdx.y;
     const double *dg = dall + ch * (size_t)ldn, *eg = eall + ch * (size_t)ldn;
     double *wout = wall + ch * (size_t)ldw;
+    // the rows that do not fit the LDS: every workgroup of a channel writes the same values to the channel's slice
+    double2 *gt = gtail ? gtail + ch * (size_t)(np + 1) : nullptr;
     double gl = 1e300, gu = -1e300;
     for (int i = tid; i < n; i += TPB) {
         const double di = dg[i];
@@ -377,8 +394,10 @@ __global__ __launch_bounds__(TPB) void bisect3_kernel(int n, int ldn, const doub
         // row i of the scaled matrix with its coupling to row i-1.  Padding rows: d = 2, coupling at the floor.
         const double di = (i < n) ? dg[i] * sc : 2.0;
         const double ev = (i >= 1 && i < n) ? (eg[i - 1] * sc) : 0.0;
-        de[i] = make_double2(di, fmax(ev * ev, 1e-60));
+        const double2 row = make_double2(di, fmax(ev * ev, 1e-60));
+        if (i <= nlr) de[i] = row; else gt[i] = row;
     }
+    if (gt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's stores have reached the L2 it reads them back from
     __syncthreads();
     gl = gl * sc - 2.1 * eps * n - 1e-300;             // scaled Gershgorin interval, widened as dstebz does
     gu = gu * sc + 2.1 * eps * n + 1e-300;
@@ -392,7 +411,7 @@ __global__ __launch_bounds__(TPB) void bisect3_kernel(int n, int ldn, const doub
         int cc[EPT];
 #pragma unroll
         for (int c = 0; c < EPT; ++c) xg[c] = gl + w * ((double)(tid + TPB * c + 1) * (1.0 / (NG + 1)));
-        sturm_counts3<EPT>(de, np, xg, cc);
+        sturm_counts3<EPT>(de, np, xg, cc, gt, nlr);
 #pragma unroll
         for (int c = 0; c < EPT; ++c) cg[tid + TPB * c] = cc[c];
         __syncthreads();
@@ -421,7 +440,7 @@ __global__ __launch_bounds__(TPB) void bisect3_kernel(int n, int ldn, const doub
         }
         if (!__syncthreads_or(nun > (tail ? EPT / 2 : 0))) break;
         int cnt[EPT];
-        sturm_counts3<EPT>(de, np, mid, cnt);
+        sturm_counts3<EPT>(de, np, mid, cnt, gt, nlr);
 #pragma unroll
         for (int c = 0; c < EPT; ++c) {
             if (!done[c]) {
@@ -456,7 +475,7 @@ __global__ __launch_bounds__(TPB) void bisect3_kernel(int n, int ldn, const doub
             x[c] = 2.0;                                // idle slot: a point above the spectrum
             if (e < K) { const double a = llo[e]; x[c] = msect_point(a, lhi[e] - a, q, rp); }
         }
-        sturm_counts3<EPT>(de, np, x, cc);
+        sturm_counts3<EPT>(de, np, x, cc, gt, nlr);
 #pragma unroll
         for (int c = 0; c < EPT; ++c) cg[tid + TPB * c] = cc[c];
         __syncthreads();
@@ -684,10 +703,27 @@ int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_
     const int ept_env = opts().bisect_ept;
     int mode = (ept_env == 8) ? 8 : (ept_env == 4) ? 4 : (ept_env == 2) ? 1024 : (ept_env == 21) ? 21 : (ept_env == 5) ? 512 : 22;
     int ng = (mode == 4) ? 1024 : (mode == 21 ? 512 : (mode == 22 ? 1024 : 2048));
-    if (bisect3_lds_bytes(n, ng) > 150 * 1024) { mode = 4; ng = 1024; }          // n = 8192: 146 KB with 1024 slots
-    const size_t lds3 = bisect3_lds_bytes(n, ng);
+    if (bisect3_lds_bytes(n, ng) > 150 * 1024) { mode = 22; ng = 1024; }         // n = 8192: 146 KB with 1024 slots
+    // Matrices whose rows do not fit the LDS beside the slot arrays (n > 8672 with 1024 slots): the first nl rows in LDS, the
+    // rest in a global array the kernel writes and reads back through the L2 (sturm_counts3); nl a multiple of HW.
+    const int np3 = (n + HW - 1) / HW * HW;
+    int nl = np3;
+    while (bisect3_lds_bytes(nl, ng) > 150 * 1024) nl -= HW;
+    const size_t lds3 = bisect3_lds_bytes(nl, ng);
     const size_t lds = (size_t)2 * (n + 3 * RS + HW) * sizeof(double);    // variants 1 and 2
-    if (lds3 > 150 * 1024) return BSP_ERR_UNSUPPORTED;
+    static double2 *g_tail = nullptr;                                      // per process, grown on demand (stage-level scratch)
+    static size_t g_tail_cap = 0;
+    double2 *gtail = nullptr;
+    if (nl < np3) {
+        const size_t need = (size_t)batch * (np3 + 1);
+        if (need > g_tail_cap) {
+            if (g_tail) { BSP_HIP(hipStreamSynchronize(st)); (void)hipFree(g_tail); g_tail = nullptr; g_tail_cap = 0; }
+            BSP_HIP(hipMalloc(reinterpret_cast<void **>(&g_tail), need * sizeof(double2)));
+            g_tail_cap = need;
+        }
+        gtail = g_tail;
+        if (opts().bisect < 3) return BSP_ERR_UNSUPPORTED;                  // the older counting kernels keep the whole matrix in LDS
+    }
     static bool attr_set = false;
     const int variant = opts().bisect;
     if (!attr_set) {
@@ -716,12 +752,12 @@ int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_
     else {
         const dim3 g3((n + ng - 1) / ng, batch);
         const int tail = opts().bisect_tail;
-        if (mode == 512) hipLaunchKernelGGL((bisect3_kernel<4, 512>), g3, dim3(512), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
-        else if (mode == 1024) hipLaunchKernelGGL((bisect3_kernel<2, 1024>), g3, dim3(1024), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
-        else if (mode == 8) hipLaunchKernelGGL((bisect3_kernel<8, 256>), g3, dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
-        else if (mode == 21) hipLaunchKernelGGL((bisect3_kernel<2, 256>), g3, dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
-        else if (mode == 22) hipLaunchKernelGGL((bisect3_kernel<2, 512>), g3, dim3(512), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
-        else hipLaunchKernelGGL((bisect3_kernel<4, 256>), g3, dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail);
+        if (mode == 512) hipLaunchKernelGGL((bisect3_kernel<4, 512>), g3, dim3(512), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail, gtail, nl);
+        else if (mode == 1024) hipLaunchKernelGGL((bisect3_kernel<2, 1024>), g3, dim3(1024), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail, gtail, nl);
+        else if (mode == 8) hipLaunchKernelGGL((bisect3_kernel<8, 256>), g3, dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail, gtail, nl);
+        else if (mode == 21) hipLaunchKernelGGL((bisect3_kernel<2, 256>), g3, dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail, gtail, nl);
+        else if (mode == 22) hipLaunchKernelGGL((bisect3_kernel<2, 512>), g3, dim3(512), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail, gtail, nl);
+        else hipLaunchKernelGGL((bisect3_kernel<4, 256>), g3, dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail, gtail, nl);
     }
     BSP_HIP(hipGetLastError());
     return BSP_OK;

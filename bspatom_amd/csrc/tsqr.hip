@@ -327,7 +327,11 @@ __global__ __launch_bounds__(256, MINW) void tsqr_tree_kernel(TsqrArgs g)
     if (top > 0) {
         {   // X = top block of leaf 0's Q
             const double *Q0 = Qall + (long)pl.base[0] * (TR * TB);
-            for (int idx = tid; idx < TB * TB; idx += 256) X[(idx & 63) + XS * (idx >> 6)] = Q0[(idx & 63) + TR * (idx >> 6)];
+            double tmp[16];                               // all 16 loads of a thread in flight, then the LDS writes
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int idx = tid + 256 * u; tmp[u] = Q0[(idx & 63) + TR * (idx >> 6)]; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int idx = tid + 256 * u; X[(idx & 63) + XS * (idx >> 6)] = tmp[u]; }
         }
         tq_bar();
         for (int l = 1; l <= top; ++l) {             // X <- X . (top block of the level-l node 0's Q); the root's is in Y
@@ -570,7 +574,11 @@ __global__ __launch_bounds__(256, MINW) void tsqr_apply_kernel(TsqrArgs g)
     // children); B U^-1 -> BV, BV T -> BW (row-major, the layout the MFMA B fragments are read in)
     double *BV, *BW;
     if (pl.nlev == 1) {
-        for (int idx = tid; idx < TB * TB; idx += 256) M0[(idx >> 6) * BS + (idx & 63)] = Ui[idx];
+        double tmp[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) tmp[u] = Ui[tid + 256 * u];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int idx = tid + 256 * u; M0[(idx >> 6) * BS + (idx & 63)] = tmp[u]; }
         tq_bar();
         __syncthreads();
         BV = M0; BW = M1;
@@ -580,7 +588,11 @@ __global__ __launch_bounds__(256, MINW) void tsqr_apply_kernel(TsqrArgs g)
         {
             const int k = idx & 3; idx >>= 2;
             const double *Qp = Qall + (long)(pl.base[1] + idx) * (TR * TB) + TB * k;
-            for (int e = tid; e < TB * TB; e += 256) cur[(e & 63) * BS + (e >> 6)] = Qp[(e & 63) + TR * (e >> 6)];
+            double tmp[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int e = tid + 256 * u; tmp[u] = Qp[(e & 63) + TR * (e >> 6)]; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int e = tid + 256 * u; cur[(e & 63) * BS + (e >> 6)] = tmp[u]; }
         }
         tq_bar();
         __syncthreads();
@@ -604,12 +616,16 @@ __global__ __launch_bounds__(256, MINW) void tsqr_apply_kernel(TsqrArgs g)
         const double *Rr = scr + g.offR + (long)pl.base[pl.nlev - 1] * (TB * TB);
         const double *Sm = scr + g.offS;
         const int row0 = TR * leaf;
-        for (int e = tid; e < TR * TB; e += 256) {
-            const int r = row0 + (e & 255), c = e >> 8;
-            if (r < g.m) {
-                double v = 0.0;
-                if (r < TB && r <= c) v = Sm[r] * Rr[r + TB * c];
-                P[r + ld * c] = v;
+        // thread = one row of the block: 64 stores of zero (or of S' R in the top 64 rows), no loads outside the top block
+        const int r = row0 + tid;
+        if (r < g.m) {
+            if (r < TB) {
+                const double sr = Sm[r];
+#pragma unroll 8
+                for (int c = 0; c < TB; ++c) P[r + ld * c] = r <= c ? sr * Rr[r + TB * c] : 0.0;
+            } else {
+#pragma unroll 8
+                for (int c = 0; c < TB; ++c) P[r + ld * c] = 0.0;
             }
         }
     }

@@ -24,7 +24,17 @@ extern "C" {
 #define BSPATOM_ERR_ARG (-2)         /* invalid argument */
 #define BSPATOM_ERR_BSPLVB (-3)      /* 'FATAL ERROR - BSPLVB' STOP of bsplvb.f90:30-34 */
 #define BSPATOM_ERR_NOGPU (-4)       /* no gfx950 device: there is no CPU fallback */
-#define BSPATOM_ERR_UNSUPPORTED (-5)
+#define BSPATOM_ERR_UNSUPPORTED (-5)  /* a size outside this build's limits (below), or a switch combination that has no kernel */
+
+/* Size limits of this build (bspatom_problem_create / bspatom_host_setup return BSPATOM_ERR_UNSUPPORTED beyond them, with the
+ * limit on stderr).  The reference allocates everything by nfun / nkp (matrices.f90:20,222-225; bsplvb.f90:22) and has no
+ * such limits, except that its Enl.dat record is I4 (matrices.f90:391): nfun <= 9999 is all it can write.
+ *   BSPATOM_MAX_NFUN  functions per channel: 10048 (npad; every nfun the reference's output format allows);
+ *   BSPATOM_MAX_K     B-spline order k (device tables of the assembly, band half-width of the Cholesky / inverse iteration);
+ *   BSPATOM_MAX_KA    Gauss-Legendre points per interval (ka = k + 3 by default: 19 at k = 16). */
+#define BSPATOM_MAX_NFUN 10048
+#define BSPATOM_MAX_K 16
+#define BSPATOM_MAX_KA 32
 
 /* Namelist values of VARS_BSP / VARS_TISE (src/ReadInputs.f90:15-17) with the reference's
  * defaults (:27-36, :75-84) as the zero-initialised-then-`bspatom_input_defaults` state. */

@@ -629,12 +629,69 @@ def test_panel_qr_first_kernel_matches_second():
 
 
 def test_sizes_beyond_the_build_are_refused_at_create():
-    """nfun > 8256: the panel of the dense -> band stage no longer fits one workgroup and the tridiagonal matrix no longer
-    fits the LDS of the bisection; refused when the problem is created (BSPATOM_ERR_UNSUPPORTED), not in the middle of a solve."""
+    """The limits of include/bspatom.h (BSPATOM_MAX_NFUN = 10048: every nfun the reference's I4 output format allows, matrices.f90:391;
+    BSPATOM_MAX_K = 16) are refused when the problem is created (BSPATOM_ERR_UNSUPPORTED = -5, the limit on stderr), not in
+    the middle of a solve; a size just inside is accepted.  Rounds 1-2 stopped at nfun = 8256 (one workgroup per panel, the
+    tridiagonal matrix in LDS); now panels above 8192 rows take the many-workgroup factorisation (csrc/tsqr.hip) and the
+    bisection serves the rows beyond the LDS from global memory (csrc/tridiag.hip)."""
     with pytest.raises(capi.BspAtomError) as ei:
-        capi.Problem(capi.make_input(kind_grid=0, rb=800.0, k=9, nfun=8320))
+        capi.Problem(capi.make_input(kind_grid=0, rb=800.0, k=9, nfun=10049))
     assert ei.value.code == -5
-    capi.Problem(capi.make_input(kind_grid=0, rb=800.0, k=9, nfun=8256)).close()
+    with pytest.raises(capi.BspAtomError) as ei:
+        capi.Problem(capi.make_input(kind_grid=0, rb=100.0, k=17, nfun=64))
+    assert ei.value.code == -5
+    capi.Problem(capi.make_input(kind_grid=0, rb=800.0, k=9, nfun=10048)).close()
+    capi.Problem(capi.make_input(kind_grid=0, rb=100.0, k=16, nfun=64)).close()
+
+
+def test_largest_size_the_reference_can_write():
+    """nfun = 9999, the largest the reference's output format allows (matrices.f90:391: I4), hydrogen, k = 9, rb = 2000, two
+    channels.  No reference run at this size exists (its DSYGV would take ~45 min per channel): the spectra are checked against
+    the 113-bit truth of exactly the pencil the product assembled (oracle/truth_quad.c on the oracle's bands, which the product
+    reproduces bit for bit -- asserted here), at the lowest 8, the 24 eigenvalues nearest zero and 16 spread over the spectrum,
+    with the bars of the smaller cases: 1e-10 relative except next to zero, where the absolute error must stay below
+    0.5 eps lambda_max (LAPACK's own level there is 0.01 .. 0.3); Rydberg series n <= 8; sorted; the consumed eigenvector
+    (on-demand path: the one-workgroup eigenvalue kernel does not fit) against its banded residual."""
+    import oracle as orc
+    from oracle import truth as qt
+    kw = dict(kind_grid=0, ra=0.0, rb=2000.0, k=9, nfun=9999, l_fin=1, n0_ini=2, l_ini=1, zatom=1.0)
+    prob = capi.Problem(capi.make_input(**kw))
+    assert prob.nfun == 9999 and prob.npad == 10048
+    E, info = prob.solve(0, 2)
+    assert np.all(info == 0) and np.all(np.diff(E, axis=1) >= 0)
+    note("n = 9999 timing %s" % prob.last_timing())
+    c = orc.make_cfg(**kw)
+    rt, aind, xg, wg = orc.grid(c)
+    SBo, HBo = orc.assemble_bands(c, rt, aind, xg, wg, 0, 2)
+    v = prob.eigvec(1, 2)
+    SB, HB = prob.assemble(0, 2)
+    assert np.array_equal(SB, SBo) and np.array_equal(HB, HBo)
+    eps = np.finfo(float).eps
+    for l in range(2):
+        lam = float(np.max(np.abs(E[l])))
+        near = np.argsort(np.abs(E[l]))[:24]
+        idx = np.unique(np.concatenate([np.arange(8), near, np.linspace(0, 9998, 16).astype(int)])).astype(np.int32)
+        hi, lo = qt.band_eigs(SBo, HBo[l], idx, E[l][idx], lam, rtol=1e-17)
+        err = np.abs(E[l][idx] - hi)
+        rel = err / np.abs(hi)
+        nz = np.isin(idx, near)
+        note("n = 9999 l=%d: vs 113-bit truth at %d eigenvalues: worst rel %.2e (away from zero %.2e), next to zero abs/(eps lam) %.4f"
+             % (l, len(idx), rel.max(), rel[~nz].max(), err[nz].max() / (eps * lam)))
+        assert np.all(rel[~nz] <= 1e-10) and err[nz].max() <= 0.5 * eps * lam
+        nq = np.arange(1, 9) + l
+        assert np.max(np.abs(E[l, :8] + 0.5 / nq ** 2) * 2 * nq ** 2) < 1e-9
+    # the eigenvector (l = 1, n0 = 2): residual of the banded pencil, S-norm 1
+    n, k = prob.nfun, prob.k
+    def bmv(Bd, x):
+        y = Bd[0] * x
+        for d in range(1, k):
+            y[:-d] += Bd[d, :n - d] * x[d:]
+            y[d:] += Bd[d, :n - d] * x[:-d]
+        return y
+    Sv = bmv(SBo, v)
+    assert abs(v @ Sv - 1.0) < 1e-12
+    assert np.max(np.abs(bmv(HBo[1], v) - E[1, 1] * Sv)) < 1e-11 * np.max(np.abs(E[1]))
+    prob.close()
 
 
 def test_graft_entry_smoke():
