@@ -280,7 +280,8 @@ def run(args):
 
     # one more, UNTIMED step of the main sharding with HIP events around every launch of the big kernels (option "ktime")
     ktimes = None
-    if not selftest and nl > 0:
+    kstage = None
+    if not selftest and nl > 0 and not args.no_kernel_timing:
         capi.set_option("ktime", 1)
         prob.solve_dev(main["l0"], nl, E_dev.data_ptr())
         ktimes = capi.kernel_times()
@@ -452,6 +453,9 @@ def main():
                          "--channels in total, --channels/N per GPU.  At N > 1 the other one is measured too and reported beside it")
     ap.add_argument("--cpu-sample-nfun", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="skip the extra untimed step that brackets every launch with HIP events (profiler runs: the trace should hold "
+                         "the timed steps only)")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU rehearsal of the N-rank launch path (gloo, stand-in spectra, no GPU, no solve): tests only")
     args = ap.parse_args()

@@ -97,8 +97,8 @@ struct GemmDesc {
     // gemm2 MODE 1: the valid tiles are enumerated in 8 x 8 super-blocks; entry s = super-block (sbx, sby) in tile
     // units / 8, sbpre = number of valid tiles up to and including it (set by syr2k_lower_f64)
     int nsb, toff;           // toff: first tile (of the enumeration) of this launch; lower_only = number of tiles in it
-    unsigned short sbpre[80];
-    unsigned char sbx[80], sby[80];
+    int sbpre[80];           // dwords: a uniform index then reads them with scalar loads (16-bit entries made the tile search a
+    int sbxy[80];            // chain of dependent VECTOR loads, ~3 us at the head of every workgroup); sbxy = sbx | sby << 8
 };
 int gemm_f64(const GemmDesc &g, hipStream_t st);
 // C = alpha * A B + beta * C with the K range cut into `splits` slices that run as separate workgroups (for products

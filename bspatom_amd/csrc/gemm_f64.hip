@@ -419,18 +419,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int id = blockIdx.x, xcd = id & 7, q = id >> 3;
         const int nb = (g.N + BN - 1) / BN, T = g.lower_only;           // T: valid tiles per channel (from the launcher)
         const int zi = q / T;
-        int t = q - zi * T + g.toff;
+        int t = __builtin_amdgcn_readfirstlane(q - zi * T + g.toff);    // uniform: the table below is read through the scalar cache
         bz = xcd + 8 * zi;
         if (bz >= g.batch) return;
-        const int ylo = g.yoff, part1 = (g.yoff == 0 && g.nsb > 0 && (int)g.sbpre[g.nsb - 1] == nb);   // part 1 of the look-ahead: by == 0 only
+        const int ylo = g.yoff, part1 = (g.yoff == 0 && g.nsb > 0 && g.sbpre[g.nsb - 1] == nb);   // part 1 of the look-ahead: by == 0 only
         // Within a channel the tiles go in 8 x 8 SUPER-BLOCKS (row-major inside): the 64 workgroups an XCD holds at a
         // time then share 8 row slices and 8 column slices of the [V|Z|V] panels (2 MB, L2-resident) instead of one
         // row slice and up to 32 column slices that each serve a single tile before the streaming C tiles evict them.
         int sb = 0;
-        while (t >= (int)g.sbpre[sb]) ++sb;
-        if (sb) t -= (int)g.sbpre[sb - 1];
-        const int sy0 = 8 * (int)g.sby[sb];
-        bx = 8 * (int)g.sbx[sb];
+        while (t >= g.sbpre[sb]) ++sb;
+        if (sb) t -= g.sbpre[sb - 1];
+        const int sxy = g.sbxy[sb];
+        const int sy0 = 8 * (sxy >> 8);
+        bx = 8 * (sxy & 255);
         for (;;) {
             const int yhi = part1 ? 0 : ((bx + 1 < nb - 1) ? bx + 1 : nb - 1);
             const int lo = (ylo > sy0) ? ylo : sy0, hi = (yhi < sy0 + 7) ? yhi : sy0 + 7;
@@ -655,7 +656,7 @@ int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const doub
             }
             if (c == 0) continue;
             T += c;
-            g.sbx[g.nsb] = (unsigned char)sx; g.sby[g.nsb] = (unsigned char)sy; g.sbpre[g.nsb] = (unsigned short)T;
+            g.sbxy[g.nsb] = sx | (sy << 8); g.sbpre[g.nsb] = T;
             ++g.nsb;
         }
     if (T <= 0) return BSP_OK;

@@ -99,11 +99,17 @@ def test_host_setup_rejects_bad_input():
     for kw in (dict(kind_grid=0, rb=0.0, k=7, nfun=64), dict(kind_grid=0, ra=60.0, rb=50.0, k=7, nfun=64),
                dict(kind_grid=0, rb=float("nan"), k=7, nfun=64), dict(kind_grid=0, rb=50.0, zatom=float("inf"), k=7, nfun=64),
                dict(kind_grid=1, ra=0.0, rb=0.005, k=7, nfun=64), dict(kind_grid=0, rb=50.0, k=7, nfun=64, n0_ini=0),
-               dict(kind_grid=0, rb=50.0, k=7, nfun=64, l_ini=-1), dict(kind_grid=0, rb=50.0, k=7, nfun=64, ka=100),
+               dict(kind_grid=0, rb=50.0, k=7, nfun=64, l_ini=-1),
                dict(kind_grid=2, rb=50.0, rmax=100.0, k=7, nfun=64), dict(kind_grid=0, rb=50.0, k=7, nfun=64, kind_pot=7)):
         with pytest.raises(capi.BspAtomError) as ei:
             capi.host_setup(capi.make_input(**kw))
         assert ei.value.code == -2, kw
+    # sizes the reference accepts and this build does not (include/bspatom.h: BSPATOM_MAX_K, BSPATOM_MAX_KA): UNSUPPORTED (-5),
+    # not an argument error -- the input is valid, the limit is the build's
+    for kw in (dict(kind_grid=0, rb=50.0, k=7, nfun=64, ka=100), dict(kind_grid=0, rb=50.0, k=17, nfun=64)):
+        with pytest.raises(capi.BspAtomError) as ei:
+            capi.host_setup(capi.make_input(**kw))
+        assert ei.value.code == -5, kw
 
 
 def test_namelist_reference_input():

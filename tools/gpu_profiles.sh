@@ -2,10 +2,10 @@
 set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -o m -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/mfma.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing > $O/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing > $O/write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -o m -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing > $O/mfma.log 2>&1
 cd $R
 python3 tools/pmc_summary.py $O/fetch $O/write $O/pmc_summary.json 128 4096 > $O/pmc_summary.txt
 python3 tools/mfma_util.py $O/mfma $O/mfma_util.json > $O/mfma_util.txt
