@@ -509,6 +509,19 @@ __device__ __forceinline__ double rsum16(double x)
     x += dppd<0x140>(x);
     return x;
 }
+// four row sums at once: the same four operations per value as rsum16 (the same bits), the four dependent chains interleaved so
+// that the DPP hazard slots and the add latencies of one are filled by the others (back to back the compiler pads them with s_nop)
+__device__ __forceinline__ void rsum16x4(double (&x)[4])
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x[q] += dppd<0xB1>(x[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x[q] += dppd<0x4E>(x[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x[q] += dppd<0x141>(x[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x[q] += dppd<0x140>(x[q]);
+}
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Householder parameters from alpha and the squared norm of the rest (> 0), with IEEE sqrt and divisions.  (v_rsq_f64 /
@@ -568,19 +581,27 @@ __device__ __forceinline__ void chase_item(double *Lw, double *pS, int r0, int c
     for (int j = 0; j < 4; ++j) vc[j] = (4 * g + j) == 0 ? 1.0 : xc[j] * scale;
     if (g == 0) Lw[ix] = r == 0 ? beta : 0.0;
     if (k > 0) {                                          // rest of the bulge tile: B <- H B
-        for (int j = 0; j < 4; ++j) {
-            const double dot = rsum16(v * b[j]);
-            if (4 * g + j > 0) Lw[ib[j]] = b[j] - tq * dot * v;
-        }
+        double d4[4];
+        for (int j = 0; j < 4; ++j) d4[j] = v * b[j];
+        rsum16x4(d4);
+        for (int j = 0; j < 4; ++j)
+            if (4 * g + j > 0) Lw[ib[j]] = b[j] - tq * d4[j] * v;
     }
-    for (int j = 0; j < 4; ++j) {                          // next bulge tile: B' <- B' H
-        const double q = tq * rsum16(bt[j] * v);
-        Lw[it[j]] = bt[j] - q * v;
+    {                                                     // next bulge tile: B' <- B' H
+        double q4[4];
+        for (int j = 0; j < 4; ++j) q4[j] = bt[j] * v;
+        rsum16x4(q4);
+        for (int j = 0; j < 4; ++j) {
+            const double q = tq * q4[j];
+            Lw[it[j]] = bt[j] - q * v;
+        }
     }
     // diagonal tile, two-sided: p = tau D v by columns (D is symmetric), by rows through pS
     double pc[4], part = 0.0;
+    for (int j = 0; j < 4; ++j) pc[j] = v * dv[j];
+    rsum16x4(pc);
     for (int j = 0; j < 4; ++j) {
-        pc[j] = tq * rsum16(v * dv[j]);
+        pc[j] = tq * pc[j];
         part += vc[j] * pc[j];
     }
     if (r < 4) pS[4 * g + r] = r == 0 ? pc[0] : (r == 1 ? pc[1] : (r == 2 ? pc[2] : pc[3]));
