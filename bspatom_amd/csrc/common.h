@@ -55,6 +55,8 @@ struct Options {
     int bisect_tail = 1;         // BSP_BISECT_TAIL: 0 = lock-step bisection to the end (no multisection tail), for A/B timing
     int no_eigvec_prefetch = 0;
     int sb2sb_mfma = 1;          // 1: block-chasing item on the matrix cores (sbr2.hip); 0: the first, all-VALU kernel (cross-check)
+    int sb16_rows = 1;           // BSP_SB16_ROWS: 1 = band 16 -> 1 with a whole chase item per DPP row, four sweeps per wave (sbr2.hip); 0 = the
+                                 // first layout (one tile spread over a wave), kept as the cross-check
     int poison_c = 0;            // test hook: fill the dense C buffer with NaN bit patterns before every solve (nothing outside the
                                  // blocks the standard form writes may ever be read)
     int ktime = 0;               // 1: HIP events around every launch of the kernels in KSlot (bspatom_kernel_times; bench.py's

@@ -827,6 +827,357 @@ __global__ __launch_bounds__(576) void sb16st_kernel(int n, int npad, int batch,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// step 2, rows layout (round 3; BSP_SB16_ROWS=1, the default; sb16st_kernel above stays as the cross-check).
+// The first layout spreads ONE 16 x 16 tile over a wave (4 values per lane) and pays for it in instructions: ~400 per item, 144
+// of them DPP steps of 12 row sums, most of the rest addresses; eight waves of it fill the CU's issue slots.  Here a DPP row of
+// 16 lanes owns an item and a wave runs FOUR sweeps (row g: sweep 4 grp + g of the pass, three items apart as before -- the
+// items of a step are independent whichever wave they sit in).  A lane holds 16 values of a tile, chosen so that every product
+// with the reflector is a sum INSIDE the lane:
+//   bulge tile B <- H B        lane j = column j (rows 0..15):  y_j = v^T B(:, j),      B(:, j)  -= tau y_j v
+//   next tile   B' <- B' H     lane i = row i (columns 0..15):  y_i = B'(i, :) v,       B'(i, :) -= tau y_i v^T
+//   diagonal    D <- H D H     lane j = column j, its upper part through the symmetry:  p = tau D v, z = p - (tau/2)(v^T p) v,
+//                              D(:, j) -= v z_j + z v_j   (one 16-lane sum for v^T p; z goes round through LDS)
+// Two waves share the items of four sweeps.  Role 0 takes B' -- and with it the NEXT item's reflector: the column that item
+// annihilates is the first column of the updated B', element j in lane j, so its norm is one row sum; beta, tau and v are formed
+// right there, (beta, 0, .., 0) goes into the window in place of the column and (v, tau) into an exchange slot (two per sweep,
+// by step parity), while the rest of the tile is still being updated: the square root and the two divisions, the longest
+// dependent chain of an item, leave the start of the next step.  Role 1 takes D and B.  At the start of a step both roles read
+// (v, tau) of their item from the slot as a broadcast.  The first item of a sweep: role 0 forms its reflector from the band
+// column one step ahead (the column is final by then and nobody reads it in between, tools/proto_sbr.py).
+constexpr int NCW4 = 4, SB16R_THREADS = (NCW4 + 1) * 64;
+constexpr int SB16R_Z = WCOLS * WROWS;                 // z of the diagonal-tile waves [2 groups][4 rows][16]
+constexpr int SB16R_DUMP = SB16R_Z + 128;              // target of masked stores [4 waves][4 rows][16]
+constexpr int SB16R_XS = SB16R_DUMP + 256;             // exchange slots [2 parities][8 sweeps][32]: v (16), tau, padding
+constexpr int SB16R_MODE = SB16R_XS + 512;
+constexpr int SB16R_LDS = (SB16R_MODE + 2) * 8;
+
+// two row sums at once (the chains interleaved, same operations per value as rsum16)
+__device__ __forceinline__ void rsum16x2(double &a, double &b)
+{
+    a += dppd<0xB1>(a); b += dppd<0xB1>(b);
+    a += dppd<0x4E>(a); b += dppd<0x4E>(b);
+    a += dppd<0x141>(a); b += dppd<0x141>(b);
+    a += dppd<0x140>(a); b += dppd<0x140>(b);
+}
+
+// The reflector of the column whose element j is x0 in lane j of the row: v and tau into the slot xw, beta (lane 0) resp. zeros
+// into the window at index hx (the column's own place).  Branch-free: a column that is zero below its first element gives
+// tau = 0, v = e_0, beta = alpha.
+__device__ __forceinline__ void next_reflector(double *Lw, const double x0, const int j, const int xw, const int hx)
+{
+    double nrm2 = j > 0 ? x0 * x0 : 0.0, alpha = j == 0 ? x0 : 0.0;
+    rsum16x2(nrm2, alpha);
+    const bool nz = nrm2 != 0.0;
+    const double beta0 = -copysign(sqrt(fma(alpha, alpha, nz ? nrm2 : 1.0)), alpha);      // never zero
+    const double tq0 = (beta0 - alpha) / beta0, scale0 = 1.0 / (alpha - beta0);
+    const double beta = nz ? beta0 : alpha, tq = nz ? tq0 : 0.0, scale = nz ? scale0 : 0.0;
+    Lw[xw + j] = j == 0 ? 1.0 : x0 * scale;
+    if (j == 0) Lw[xw + 16] = tq;
+    Lw[hx] = j == 0 ? beta : 0.0;
+}
+
+// role 0: next tile of item r0 (FAST: its 16 columns do not wrap around the ring); (v, tau) from slot xr
+template <bool FAST>
+__device__ __forceinline__ void chase4_next(double *Lw, const int r0, const int j, const int xr, const int xw)
+{
+    double v[16], bt[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = Lw[xr + i];
+    const double tq = Lw[xr + 16];
+    int at[16];                                                      // row r0 + 16 + j, columns r0 + i
+    if (FAST) {
+        const int a0 = ((r0 & (WCOLS - 1)) << 5) + 16 + j;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) at[i] = a0 + 31 * i;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) at[i] = (((r0 + i) & (WCOLS - 1)) << 5) + (16 + j - i);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bt[i] = Lw[at[i]];
+    double y0 = bt[0], y1 = v[1] * bt[1], y2 = v[2] * bt[2], y3 = v[3] * bt[3];
+#pragma unroll
+    for (int i = 4; i < 16; i += 4) {
+        y0 = fma(v[i], bt[i], y0); y1 = fma(v[i + 1], bt[i + 1], y1);
+        y2 = fma(v[i + 2], bt[i + 2], y2); y3 = fma(v[i + 3], bt[i + 3], y3);
+    }
+    const double ct = tq * ((y0 + y1) + (y2 + y3));
+    next_reflector(Lw, bt[0] - ct, j, xw, at[0]);                    // B'(j, 0): element j of the next item's column
+#pragma unroll
+    for (int i = 1; i < 16; ++i) Lw[at[i]] = fma(-ct, v[i], bt[i]);
+}
+
+// role 1: diagonal tile and bulge tile of item (r0, c0); (v, tau) from slot xr
+template <bool FAST>
+__device__ __forceinline__ void chase4_diag(double *Lw, const int r0, const int c0, const bool hasB, const int j, const int xr,
+                                            const int zi, const int dumpi, const int (&offD)[16])
+{
+    double v[16], d[16], b[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = Lw[xr + i];
+    const double tq = Lw[xr + 16], vl = Lw[xr + j];
+    int ad[16];                                                      // D(i, j) from the stored triangle: 31 min(i, j) + max(i, j)
+    if (FAST) {
+        const int ud = (r0 & (WCOLS - 1)) << 5;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ad[i] = ud + offD[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            ad[i] = i >= j ? (((r0 + j) & (WCOLS - 1)) << 5) + (i - j) : (((r0 + i) & (WCOLS - 1)) << 5) + (j - i);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = Lw[ad[i]];
+    // bulge tile: column c0 + j, rows r0 .. r0 + 15 (contiguous).  Column 0 holds (beta, 0, .., 0) already and the first item of a
+    // sweep has no bulge tile: those lanes work on the dump
+    int ab = (((c0 + j) & (WCOLS - 1)) << 5) + (r0 - c0 - j);
+    if (j == 0 || !hasB) ab = dumpi;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b[i] = Lw[ab + i];
+    double y0 = d[0], y1 = v[1] * d[1], y2 = v[2] * d[2], y3 = v[3] * d[3];
+#pragma unroll
+    for (int i = 4; i < 16; i += 4) {
+        y0 = fma(v[i], d[i], y0); y1 = fma(v[i + 1], d[i + 1], y1);
+        y2 = fma(v[i + 2], d[i + 2], y2); y3 = fma(v[i + 3], d[i + 3], y3);
+    }
+    const double p = tq * ((y0 + y1) + (y2 + y3));
+    const double vtp = rsum16(vl * p);
+    const double z = fma(-(0.5 * tq * vtp), vl, p);
+    Lw[zi + j] = z;
+    // the bulge tile while z goes round
+    double w0 = b[0], w1 = v[1] * b[1], w2 = v[2] * b[2], w3 = v[3] * b[3];
+#pragma unroll
+    for (int i = 4; i < 16; i += 4) {
+        w0 = fma(v[i], b[i], w0); w1 = fma(v[i + 1], b[i + 1], w1);
+        w2 = fma(v[i + 2], b[i + 2], w2); w3 = fma(v[i + 3], b[i + 3], w3);
+    }
+    const double cb = tq * ((w0 + w1) + (w2 + w3));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Lw[ab + i] = fma(-cb, v[i], b[i]);
+    double zz[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zz[i] = Lw[zi + i];
+    // the lower triangle is what the band stores; the mirrored values go to the dump (a select on the address, no branch)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Lw[i >= j ? ad[i] : dumpi + i] = fma(-zz[i], vl, fma(-v[i], z, d[i]));
+}
+
+// One step of the data-moving wave.  Columns enter the window 16 per step, four steps after their loads were issued (PH = step
+// mod 4 selects the eight registers: nothing waits for HBM); columns leave it with plain stores, at most 16 per step.  Everything
+// that WAITS for memory comes first, while the only operations in flight are a step old; the stores of the step go out last
+// (sb16st_kernel's mover, which brings 64 columns every fourth step, is the longest wave of that step once the chasing waves
+// are short).
+template <int PH>
+__device__ __forceinline__ void mover_step(double *Lw, double *__restrict__ AB, double (&qb)[32], const int n, const int npad,
+                                           const int LB, const int RP, const int RPn, const int ps, const int lane,
+                                           const unsigned long long *pollp, unsigned long long *pubp, unsigned long long &pw,
+                                           Sb16Ctl *C, int *status)
+{
+    const int md = lane & 31, mh = lane >> 5;                       // mover lane: row md of columns 2 i + mh
+    if (PH == 0 && pollp && ps > 0 && LB + 64 < n) {               // the block about to be requested, as the pass before left it
+        const int need = LB + 128 < n ? LB + 128 : n;
+        const unsigned long long want = ((unsigned long long)(ps - 1) << 32) + (unsigned)need;
+        if (pw < want) s16_wait(pollp, want, C, status);            // pw was requested two steps ago
+        else asm volatile("buffer_inv sc1" ::: "memory");
+    }
+    {
+        const unsigned s0_ = (unsigned)(LB + mh), lim = (unsigned)(n - md);          // column c is inside while c < n - md
+#pragma unroll
+        for (int i = 8 * PH; i < 8 * PH + 8; ++i) {
+            const unsigned c = s0_ + 2 * i;
+            Lw[(((c & (WCOLS - 1)) << 5) + md)] = c < lim ? qb[i] : 0.0;
+        }
+        const unsigned o0 = (unsigned)(LB + 64 + mh) * LD + md, omax = (unsigned)(n - 1) * LD;
+#pragma unroll
+        for (int i = 8 * PH; i < 8 * PH + 8; ++i) {
+            unsigned o = o0 + 2 * LD * i;
+            o = o < omax ? o : omax;                                 // clamped, masked at the LDS write
+            qb[i] = AB[o];
+        }
+    }
+    if (PH == 3 && pubp) {                                          // everything stored before this step has reached the L2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+            __hip_atomic_store(pubp, ((unsigned long long)ps << 32) + (unsigned)RP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (PH == 2 && pollp) pw = __hip_atomic_load(pollp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        const unsigned c0_ = (unsigned)(RP + mh), dumpo = (unsigned)npad * LD + 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned c = c0_ + 2 * i;
+            const unsigned o = c < (unsigned)RPn ? c * LD + md : dumpo;
+            AB[o] = Lw[((c & (WCOLS - 1)) << 5) + md];
+        }
+    }
+}
+
+__global__ __launch_bounds__(SB16R_THREADS) void sb16r_kernel(int n, int npad, int batch, double *__restrict__ ABall,
+                                                              double *__restrict__ dall, double *__restrict__ eall,
+                                                              long long *diag, Sb16Ctl *ctl, int P, int *status, int force_abort)
+{
+    extern __shared__ double lds[];
+    double *Lw = lds;
+    long long dacc[5] = {0, 0, 0, 0, 0}, dt0 = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int grp = (wv >> 1) & 1, role = wv & 1, sw = 4 * grp + g;  // chasing waves 0 .. 3; the lane's sweep within a pass
+    const int zi = SB16R_Z + 64 * grp + 16 * g, dumpi = SB16R_DUMP + 64 * (wv & 3) + 16 * g;
+    int offD[16];
+    for (int i = 0; i < 16; ++i) offD[i] = i >= j ? 31 * j + i : 31 * i + j;
+    // ---- which channel; alone (ctl == nullptr) or member w of a ring of P workgroups
+    int chn = blockIdx.x, w = 0, stride = 1;
+    const unsigned long long *pollp = nullptr;
+    unsigned long long *pubp = nullptr;
+    Sb16Ctl *C = nullptr;
+    if (ctl) {
+        const int blk = blockIdx.x, grp = blk / (8 * P), rr = blk % (8 * P);
+        chn = grp * 8 + (rr & 7); w = rr >> 3;
+        if (chn >= batch) return;
+        C = ctl + chn;
+        int *modep = reinterpret_cast<int *>(lds + SB16R_MODE);
+        if (tid == 0) {
+            const unsigned long long xcc = (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu);   // HW_REG_XCC_ID
+            const unsigned long long mine = (0x10ull | xcc) << (8 * w);
+            unsigned long long full = 0;
+            for (int q = 0; q < P; ++q) full |= 0x10ull << (8 * q);
+            unsigned long long v = atomicOr(&C->hs, mine) | mine;
+            for (int spin = 0; !(v & (S16_COMMIT | S16_ABORT)); ++spin) {
+                if (force_abort == 1) atomicCAS(&C->hs, v, v | S16_ABORT);
+                else if ((v & full) == full) atomicCAS(&C->hs, v, v | S16_COMMIT);
+                else if (spin > 400000) atomicCAS(&C->hs, v, v | S16_ABORT);
+                else __builtin_amdgcn_s_sleep(4);
+                v = __hip_atomic_load(&C->hs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            int mode;                                     // 0 = exit, 1 = ring, 2 = alone
+            if (v & S16_ABORT) mode = (w == 0) ? 2 : 0;
+            else {
+                bool same = true;
+                for (int q = 1; q < P; ++q) same = same && (((v >> (8 * q)) & 0xfu) == (v & 0xfu));
+                if (force_abort == 2) same = false;
+                mode = same ? 1 : ((w == 0) ? 2 : 0);
+            }
+            *modep = mode;
+        }
+        __syncthreads();
+        const int mode = __builtin_amdgcn_readfirstlane(*modep);
+        __syncthreads();
+        if (mode == 0) return;
+        if (mode == 1 && P > 1) { stride = P; pollp = &C->prog[(w + P - 1) % P]; pubp = &C->prog[w]; }
+        else w = 0;
+    }
+    double *AB = ABall + (size_t)chn * ab_stride(npad);
+    const int npass = (n - 2 + NW2 - 1) / NW2;
+    for (int ps = w; ps < npass; ps += stride) {
+        const int s0 = ps * NW2;
+        int RP = s0, LP = s0 + 64;
+        if (pollp && ps > 0) {                            // the first 128 columns of this pass, as the pass before left them
+            if (tid == 0) {
+                const int need = s0 + 128 < n ? s0 + 128 : n;
+                s16_wait(pollp, ((unsigned long long)(ps - 1) << 32) + (unsigned)need, C, status);
+            }
+            __syncthreads();
+            asm volatile("buffer_inv sc1" ::: "memory");
+        }
+        for (int idx = tid; idx < 64 * WROWS; idx += SB16R_THREADS) {
+            const int c = s0 + (idx >> 5), d = idx & 31;
+            Lw[((c & (WCOLS - 1)) << 5) + d] = c + d < n ? AB[(size_t)c * LD + d] : 0.0;
+        }
+        __syncthreads();
+        // the reflector of the pass's first item (sweep s0, k = 0) into its slot of step 0
+        if (wv == 0 && g == 0) {
+            const int hx = ((s0 & (WCOLS - 1)) << 5) + 1 + j;
+            next_reflector(Lw, Lw[hx], j, SB16R_XS, hx);
+        }
+        const int nsteps = (n - s0 - 1 + B2 - 1) / B2 + LAG * (NW2 - 1);
+#define SB16R_RPN(t) \
+        int RPn = s0 + NW2 + B2 * ((t) - LAG * (NW2 - 1) - 1);   /* columns leaving: left of the trailing sweep's tiles */ \
+        if (RPn > n) RPn = n; \
+        if (RPn < RP) RPn = RP;
+        if (wv == NCW4) {                                 // the last wave moves data and does nothing else
+            double qb[32];
+            unsigned long long pw = 0;                    // the partner's progress word as last seen
+            {
+                const int md = lane & 31, mh = lane >> 5;
+                const unsigned o0 = (unsigned)(LP + mh) * LD + md, omax = (unsigned)(n - 1) * LD;
+                for (int i = 0; i < 32; ++i) {            // unmasked value; the mask is applied at the LDS write
+                    unsigned o = o0 + 2 * LD * i;
+                    o = o < omax ? o : omax;
+                    qb[i] = AB[o];
+                }
+            }
+            __syncthreads();
+#define SB16R_MSTEP(PH) \
+            if (t + PH < nsteps) { \
+                SB16R_RPN(t + PH) \
+                if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime(); \
+                mover_step<PH>(Lw, AB, qb, n, npad, LP, RP, RPn, ps, lane, pollp, pubp, pw, C, status); \
+                if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[0] += t_ - dt0; dt0 = t_; } \
+                RP = RPn; \
+                lds_only_barrier(); \
+                if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; } \
+            }
+            for (int t = 0; t < nsteps; t += 4) {
+                SB16R_MSTEP(0) SB16R_MSTEP(1) SB16R_MSTEP(2) SB16R_MSTEP(3)
+                LP += 64;
+            }
+#undef SB16R_MSTEP
+            LP = s0 + 64;
+        } else {
+            __syncthreads();
+            for (int t = 0; t < nsteps; ++t) {
+                SB16R_RPN(t)
+                RP = RPn;
+                if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime();
+                // row g of the wave: sweep s0 + sw, item t - 3 sw
+                const int s4 = s0 + sw, k4 = t - LAG * sw, r04 = s4 + 1 + B2 * k4;
+                const bool act = k4 >= 0 && s4 < n - 2 && r04 < n;
+                // a row whose diagonal / next tile wraps around the ring sends the wave through the general addresses
+                const bool slow = __builtin_amdgcn_ballot_w64(act && (r04 & (WCOLS - 1)) > WCOLS - 16) != 0;
+                const int xr = SB16R_XS + (((t & 1) * 8 + sw) << 5), xw = SB16R_XS + ((((t + 1) & 1) * 8 + sw) << 5);
+                if (role == 0) {
+                    if (act) {
+                        if (!slow) chase4_next<true>(Lw, r04, j, xr, xw);
+                        else chase4_next<false>(Lw, r04, j, xr, xw);
+                    } else if (k4 == -1 && s4 < n - 2) {  // the sweep starts in the next step: its reflector from the band column
+                        const int hx = ((s4 & (WCOLS - 1)) << 5) + 1 + j;
+                        next_reflector(Lw, Lw[hx], j, xw, hx);
+                    }
+                } else if (act) {
+                    const int c04 = k4 == 0 ? s4 : r04 - B2;
+                    if (!slow) chase4_diag<true>(Lw, r04, c04, k4 > 0, j, xr, zi, dumpi, offD);
+                    else chase4_diag<false>(Lw, r04, c04, k4 > 0, j, xr, zi, dumpi, offD);
+                }
+                if (diag) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[2] += t_ - dt0; dt0 = t_; }
+                lds_only_barrier();
+                if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; }
+            }
+        }
+#undef SB16R_RPN
+        LP += 64 * ((nsteps + 3) / 4);                    // blocks of 64 columns that entered the window
+        __syncthreads();
+        int hi = LP < n ? LP : n;
+        for (int idx = tid; idx < (hi - RP) * WROWS; idx += SB16R_THREADS) {
+            const int c = RP + (idx >> 5), d = idx & 31;
+            AB[(size_t)c * LD + d] = Lw[((c & (WCOLS - 1)) << 5) + d];
+        }
+        __syncthreads();
+        if (pubp && tid == 0)
+            __hip_atomic_store(pubp, ((unsigned long long)ps << 32) + (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (diag && blockIdx.x == 0 && lane == 0)
+        for (int q = 0; q < 5; ++q) diag[wv * 5 + q] = dacc[q];
+    if (stride > 1 && (npass - 1) % stride != w && npass > 0) return;   // the member of the last pass has seen every pass end
+    __syncthreads();
+    asm volatile("buffer_inv sc1" ::: "memory");
+    double *dd = dall + (size_t)chn * npad, *ee = eall + (size_t)chn * npad;
+    for (int jj = tid; jj < n; jj += SB16R_THREADS) {
+        dd[jj] = AB[(size_t)jj * LD];
+        ee[jj] = jj < n - 1 ? AB[(size_t)jj * LD + 1] : 0.0;
+    }
+}
+
 }  // namespace
 
 int launch_sb2sb(int n, int npad, int batch, double *d_AB, hipStream_t st)
@@ -872,6 +1223,8 @@ int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double 
     if (!attr) {
         BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sb16st_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     SB16_LDS));
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sb16r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    SB16R_LDS));
         attr = true;
     }
     // workgroups per channel: as many as the chip has CUs for (each needs a whole CU's LDS), at most 8
@@ -897,12 +1250,15 @@ int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double 
     }
     const int nblk = P > 1 ? ((batch + 7) / 8) * 8 * P : batch;
     const int fab = opts().sb2st_force_abort;
+    const bool rows = opts().sb16_rows != 0;
     if (opts().sb2st_diag) {                                // cycles per phase of the chasing waves (workgroup 0)
         long long *dbuf = nullptr, h[45];
         BSP_HIP(hipMalloc(reinterpret_cast<void **>(&dbuf), sizeof(h)));
         BSP_HIP(hipMemsetAsync(dbuf, 0, sizeof(h), st));
-        hipLaunchKernelGGL(sb16st_kernel, dim3(nblk), dim3(576), SB16_LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf, d_ctl, P,
-                           d_status, fab);
+        if (rows) hipLaunchKernelGGL(sb16r_kernel, dim3(nblk), dim3(SB16R_THREADS), SB16R_LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf,
+                                     d_ctl, P, d_status, fab);
+        else hipLaunchKernelGGL(sb16st_kernel, dim3(nblk), dim3(576), SB16_LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf, d_ctl, P,
+                                d_status, fab);
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) { hipFree(dbuf); BSP_HIP(le); }
         BSP_HIP(hipStreamSynchronize(st));
@@ -917,8 +1273,10 @@ int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double 
         return BSP_OK;
     }
     KScope kt(KS_SB16ST, st);
-    hipLaunchKernelGGL(sb16st_kernel, dim3(nblk), dim3(576), SB16_LDS, st, n, npad, batch, d_AB, d_d, d_e, (long long *)nullptr,
-                       d_ctl, P, d_status, fab);
+    if (rows) hipLaunchKernelGGL(sb16r_kernel, dim3(nblk), dim3(SB16R_THREADS), SB16R_LDS, st, n, npad, batch, d_AB, d_d, d_e,
+                                 (long long *)nullptr, d_ctl, P, d_status, fab);
+    else hipLaunchKernelGGL(sb16st_kernel, dim3(nblk), dim3(576), SB16_LDS, st, n, npad, batch, d_AB, d_d, d_e, (long long *)nullptr,
+                            d_ctl, P, d_status, fab);
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }
