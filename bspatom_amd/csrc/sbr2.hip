@@ -838,17 +838,18 @@ __global__ __launch_bounds__(576) void sb16st_kernel(int n, int npad, int batch,
 //   next tile   B' <- B' H     lane i = row i (columns 0..15):  y_i = B'(i, :) v,       B'(i, :) -= tau y_i v^T
 //   diagonal    D <- H D H     lane j = column j, its upper part through the symmetry:  p = tau D v, z = p - (tau/2)(v^T p) v,
 //                              D(:, j) -= v z_j + z v_j   (one 16-lane sum for v^T p; z goes round through LDS)
-// Two waves share the items of four sweeps.  Role 0 takes B' -- and with it the NEXT item's reflector: the column that item
+// Three waves share the items of four sweeps.  Role 0 takes B' -- and with it the NEXT item's reflector: the column that item
 // annihilates is the first column of the updated B', element j in lane j, so its norm is one row sum; beta, tau and v are formed
 // right there, (beta, 0, .., 0) goes into the window in place of the column and (v, tau) into an exchange slot (two per sweep,
 // by step parity), while the rest of the tile is still being updated: the square root and the two divisions, the longest
-// dependent chain of an item, leave the start of the next step.  Role 1 takes D and B.  At the start of a step both roles read
-// (v, tau) of their item from the slot as a broadcast.  The first item of a sweep: role 0 forms its reflector from the band
+// dependent chain of an item, leave the start of the next step.  Role 1 takes D, role 2 takes B.  At the start of a step every role
+// reads (v, tau) of its item from the slot as a broadcast.  (The waves are bound by the latency of their dependent chains, not by
+// issue slots: one wave per SIMD and role; with D and B in one wave the step was 2860 ticks, 2475 of them that wave.)  The first item of a sweep: role 0 forms its reflector from the band
 // column one step ahead (the column is final by then and nobody reads it in between, tools/proto_sbr.py).
-constexpr int NCW4 = 4, SB16R_THREADS = (NCW4 + 1) * 64;
+constexpr int NCW4 = 6, SB16R_THREADS = (NCW4 + 1) * 64;
 constexpr int SB16R_Z = WCOLS * WROWS;                 // z of the diagonal-tile waves [2 groups][4 rows][16]
-constexpr int SB16R_DUMP = SB16R_Z + 128;              // target of masked stores [4 waves][4 rows][16]
-constexpr int SB16R_XS = SB16R_DUMP + 256;             // exchange slots [2 parities][8 sweeps][32]: v (16), tau, padding
+constexpr int SB16R_DUMP = SB16R_Z + 128;              // target of masked stores [6 waves][4 rows][16]
+constexpr int SB16R_XS = SB16R_DUMP + 384;             // exchange slots [2 parities][8 sweeps][32]: v (16), tau, padding
 constexpr int SB16R_MODE = SB16R_XS + 512;
 constexpr int SB16R_LDS = (SB16R_MODE + 2) * 8;
 
@@ -877,25 +878,28 @@ __device__ __forceinline__ void next_reflector(double *Lw, const double x0, cons
     Lw[hx] = j == 0 ? beta : 0.0;
 }
 
-// role 0: next tile of item r0 (FAST: its 16 columns do not wrap around the ring); (v, tau) from slot xr
-template <bool FAST>
-__device__ __forceinline__ void chase4_next(double *Lw, const int r0, const int j, const int xr, const int xw)
+// Window index of the element (r0 + 16 + j, r0 + i) of an item's next tile, i = 0 .. 15, as base[i] + 31 i: the column r0 + i wraps
+// around the ring from i = 512 - (r0 mod 512) on
+template <bool FAST>                                                   // FAST: no tile of the wave wraps
+__device__ __forceinline__ void next_tile_addr(const int r0, const int j, int (&at)[16])
 {
-    double v[16], bt[16];
+    const int cb = r0 & (WCOLS - 1), a0 = (cb << 5) + 16 + j, iw = WCOLS - cb;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = Lw[xr + i];
-    const double tq = Lw[xr + 16];
-    int at[16];                                                      // row r0 + 16 + j, columns r0 + i
-    if (FAST) {
-        const int a0 = ((r0 & (WCOLS - 1)) << 5) + 16 + j;
+    for (int i = 0; i < 16; ++i) at[i] = (FAST || i < iw) ? a0 : a0 - WCOLS * WROWS;
+}
+// ... of the element D(i, j) of its diagonal tile, from the stored triangle: column r0 + min(i, j) (wraps when both do), 31 min + max
+template <bool FAST>
+__device__ __forceinline__ void diag_tile_addr(const int r0, const int j, const int (&offD)[16], int (&ad)[16])
+{
+    const int cb = r0 & (WCOLS - 1), ud = cb << 5, iw = WCOLS - cb, udq = j >= iw ? ud - WCOLS * WROWS : ud;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) at[i] = a0 + 31 * i;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) at[i] = (((r0 + i) & (WCOLS - 1)) << 5) + (16 + j - i);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) bt[i] = Lw[at[i]];
+    for (int i = 0; i < 16; ++i) ad[i] = ((!FAST && i >= iw) ? udq : ud) + offD[i];
+}
+
+// role 0, the arithmetic of an item: next tile bt (lane j = row j) <- bt H, the reflector of its first column for the next item
+__device__ __forceinline__ void chase4_next(double *Lw, double (&bt)[16], const double (&v)[16], const double tq, const int (&at)[16],
+                                            const int j, const int xw)
+{
     double y0 = bt[0], y1 = v[1] * bt[1], y2 = v[2] * bt[2], y3 = v[3] * bt[3];
 #pragma unroll
     for (int i = 4; i < 16; i += 4) {
@@ -905,36 +909,17 @@ __device__ __forceinline__ void chase4_next(double *Lw, const int r0, const int 
     const double ct = tq * ((y0 + y1) + (y2 + y3));
     next_reflector(Lw, bt[0] - ct, j, xw, at[0]);                    // B'(j, 0): element j of the next item's column
 #pragma unroll
-    for (int i = 1; i < 16; ++i) Lw[at[i]] = fma(-ct, v[i], bt[i]);
+    for (int i = 1; i < 16; ++i) Lw[at[i] + 31 * i] = fma(-ct, v[i], bt[i]);
 }
 
-// role 1: diagonal tile and bulge tile of item (r0, c0); (v, tau) from slot xr
-template <bool FAST>
-__device__ __forceinline__ void chase4_diag(double *Lw, const int r0, const int c0, const bool hasB, const int j, const int xr,
-                                            const int zi, const int dumpi, const int (&offD)[16])
+// role 1: diagonal tile d (lane j = column j) <- H d H; (v, tau) from slot xr
+__device__ __forceinline__ void chase4_diag(double *Lw, const double (&d)[16], const int (&ad)[16], const int j, const int xr,
+                                            const int zi, const int dumpi)
 {
-    double v[16], d[16], b[16];
+    double v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = Lw[xr + i];
     const double tq = Lw[xr + 16], vl = Lw[xr + j];
-    int ad[16];                                                      // D(i, j) from the stored triangle: 31 min(i, j) + max(i, j)
-    if (FAST) {
-        const int ud = (r0 & (WCOLS - 1)) << 5;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) ad[i] = ud + offD[i];
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            ad[i] = i >= j ? (((r0 + j) & (WCOLS - 1)) << 5) + (i - j) : (((r0 + i) & (WCOLS - 1)) << 5) + (j - i);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) d[i] = Lw[ad[i]];
-    // bulge tile: column c0 + j, rows r0 .. r0 + 15 (contiguous).  Column 0 holds (beta, 0, .., 0) already and the first item of a
-    // sweep has no bulge tile: those lanes work on the dump
-    int ab = (((c0 + j) & (WCOLS - 1)) << 5) + (r0 - c0 - j);
-    if (j == 0 || !hasB) ab = dumpi;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) b[i] = Lw[ab + i];
     double y0 = d[0], y1 = v[1] * d[1], y2 = v[2] * d[2], y3 = v[3] * d[3];
 #pragma unroll
     for (int i = 4; i < 16; i += 4) {
@@ -945,7 +930,26 @@ __device__ __forceinline__ void chase4_diag(double *Lw, const int r0, const int 
     const double vtp = rsum16(vl * p);
     const double z = fma(-(0.5 * tq * vtp), vl, p);
     Lw[zi + j] = z;
-    // the bulge tile while z goes round
+    double zz[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zz[i] = Lw[zi + i];
+    // the lower triangle is what the band stores; the mirrored values go to the dump (a select on the address, no branch)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Lw[i >= j ? ad[i] : dumpi + i] = fma(-zz[i], vl, fma(-v[i], z, d[i]));
+}
+
+// role 2: bulge tile of item (r0, c0): column c0 + j, rows r0 .. r0 + 15 (contiguous; no wrap inside a lane).  Column 0 holds
+// (beta, 0, .., 0) already: lane 0 works on the dump
+__device__ __forceinline__ void chase4_bulge(double *Lw, const int r0, const int c0, const int j, const int xr, const int dumpi)
+{
+    double v[16], b[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = Lw[xr + i];
+    const double tq = Lw[xr + 16];
+    int ab = (((c0 + j) & (WCOLS - 1)) << 5) + (r0 - c0 - j);
+    if (j == 0) ab = dumpi;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b[i] = Lw[ab + i];
     double w0 = b[0], w1 = v[1] * b[1], w2 = v[2] * b[2], w3 = v[3] * b[3];
 #pragma unroll
     for (int i = 4; i < 16; i += 4) {
@@ -955,53 +959,52 @@ __device__ __forceinline__ void chase4_diag(double *Lw, const int r0, const int 
     const double cb = tq * ((w0 + w1) + (w2 + w3));
 #pragma unroll
     for (int i = 0; i < 16; ++i) Lw[ab + i] = fma(-cb, v[i], b[i]);
-    double zz[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) zz[i] = Lw[zi + i];
-    // the lower triangle is what the band stores; the mirrored values go to the dump (a select on the address, no branch)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) Lw[i >= j ? ad[i] : dumpi + i] = fma(-zz[i], vl, fma(-v[i], z, d[i]));
 }
 
-// One step of the data-moving wave.  Columns enter the window 16 per step, four steps after their loads were issued (PH = step
-// mod 4 selects the eight registers: nothing waits for HBM); columns leave it with plain stores, at most 16 per step.  Everything
-// that WAITS for memory comes first, while the only operations in flight are a step old; the stores of the step go out last
-// (sb16st_kernel's mover, which brings 64 columns every fourth step, is the longest wave of that step once the chasing waves
-// are short).
-template <int PH>
-__device__ __forceinline__ void mover_step(double *Lw, double *__restrict__ AB, double (&qb)[32], const int n, const int npad,
-                                           const int LB, const int RP, const int RPn, const int ps, const int lane,
-                                           const unsigned long long *pollp, unsigned long long *pubp, unsigned long long &pw,
-                                           Sb16Ctl *C, int *status)
+// Rows and columns of the band storage beyond the matrix are made zero before sb16r_kernel runs, column npad (the first of
+// the slack behind the band, ab_stride) included: the kernel's data-moving wave copies whole columns into LDS without looking
+// at them, and takes column npad for every column further right.
+__global__ void band_tail_zero_kernel(int n, int npad, double *__restrict__ ABall)
 {
-    const int md = lane & 31, mh = lane >> 5;                       // mover lane: row md of columns 2 i + mh
-    if (PH == 0 && pollp && ps > 0 && LB + 64 < n) {               // the block about to be requested, as the pass before left it
-        const int need = LB + 128 < n ? LB + 128 : n;
+    double *AB = ABall + (size_t)blockIdx.x * ab_stride(npad);
+    const int c_lo = n - (WROWS - 1) > 0 ? n - (WROWS - 1) : 0;
+    for (int idx = threadIdx.x; idx < (npad + 1 - c_lo) * WROWS; idx += blockDim.x) {
+        const int c = c_lo + (idx >> 5), d = idx & 31;
+        if (c + d >= n) AB[(size_t)c * LD + d] = 0.0;
+    }
+}
+
+// One step of the data-moving wave.  Sixteen columns enter the window per step by LDS-DMA (four instructions of 1 KB: a column
+// of the window is the first 32 rows of the band column, 256 bytes here and there; no registers, so no wait the compiler could
+// place -- with register staging it made every step wait for the loads of the step before, HBM latency, and the data-moving wave
+// was the longest of the step); they have landed four steps later (the wait at the end of the step, a literal count: the counter
+// is in order over loads and stores and a step issues 4 + 8 of them, 13 with the poll) and are first touched six steps later.
+// Columns leave the window with plain stores, at most 16 per step.
+template <int PH>
+__device__ __forceinline__ void mover_step(double *Lw, double *__restrict__ AB, const int n, const int npad, const int LP,
+                                           const int RP, const int RPn, const int RPold, const int ps, const int lane,
+                                           const unsigned long long *pollp, unsigned long long *pubp, unsigned long long &pw,
+                                           unsigned long long &ptmp, Sb16Ctl *C, int *status)
+{
+    const int md = lane & 31, mh = lane >> 5;                       // column-out lane: row md of columns 2 i + mh
+    if (PH == 0 && pollp && ps > 0 && LP < n) {                    // the 64 columns requested in these four steps, as the pass before left them
+        const int need = LP + 64 < n ? LP + 64 : n;
         const unsigned long long want = ((unsigned long long)(ps - 1) << 32) + (unsigned)need;
-        if (pw < want) s16_wait(pollp, want, C, status);            // pw was requested two steps ago
+        if (pw < want) s16_wait(pollp, want, C, status);            // pw was requested three steps ago
         else asm volatile("buffer_inv sc1" ::: "memory");
     }
-    {
-        const unsigned s0_ = (unsigned)(LB + mh), lim = (unsigned)(n - md);          // column c is inside while c < n - md
 #pragma unroll
-        for (int i = 8 * PH; i < 8 * PH + 8; ++i) {
-            const unsigned c = s0_ + 2 * i;
-            Lw[(((c & (WCOLS - 1)) << 5) + md)] = c < lim ? qb[i] : 0.0;
-        }
-        const unsigned o0 = (unsigned)(LB + 64 + mh) * LD + md, omax = (unsigned)(n - 1) * LD;
-#pragma unroll
-        for (int i = 8 * PH; i < 8 * PH + 8; ++i) {
-            unsigned o = o0 + 2 * LD * i;
-            o = o < omax ? o : omax;                                 // clamped, masked at the LDS write
-            qb[i] = AB[o];
-        }
+    for (int q = 0; q < 4; ++q) {                                   // columns LP + 4 q .. + 3: lane = (column lane >> 4, rows 2 (lane & 15), + 1)
+        const int c = LP + 4 * q, cl = c + (lane >> 4);
+        const double *src = AB + (size_t)(cl < npad ? cl : npad) * LD + 2 * (lane & 15);
+        double *dst = Lw + ((c & (WCOLS - 1)) << 5);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     }
-    if (PH == 3 && pubp) {                                          // everything stored before this step has reached the L2
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0)
-            __hip_atomic_store(pubp, ((unsigned long long)ps << 32) + (unsigned)RP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (PH == 2 && pollp) pw = __hip_atomic_load(pollp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The partner's progress word: requested here, looked at two steps later.  The load is hidden from the compiler (it would wait
+    // for it with a count that also covers the DMA just issued); a value read too early is an OLDER progress, which only
+    // sends the check above into its polling loop.
+    if (PH == 1 && pollp) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "+v"(ptmp) : "v"(pollp) : "memory");
     {
         const unsigned c0_ = (unsigned)(RP + mh), dumpo = (unsigned)npad * LD + 64 + lane;
 #pragma unroll
@@ -1010,6 +1013,16 @@ __device__ __forceinline__ void mover_step(double *Lw, double *__restrict__ AB, 
             const unsigned o = c < (unsigned)RPn ? c * LD + md : dumpo;
             AB[o] = Lw[((c & (WCOLS - 1)) << 5) + md];
         }
+    }
+    // All but the 48 youngest operations complete: the columns requested FOUR steps ago are in the window, and the stores of
+    // that step have reached the L2 -- the columns left of RPold, progress for the member that runs the next pass.  (Two steps
+    // were not enough: a step is shorter than half the latency of HBM and the wave waited for it every time.)
+    asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    if (PH == 3 && pubp && lane == 0)
+        __hip_atomic_store(pubp, ((unsigned long long)ps << 32) + (unsigned)RPold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (PH == 3 && pollp) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ptmp), hi = __builtin_amdgcn_readfirstlane((unsigned)(ptmp >> 32));
+        pw = ((unsigned long long)hi << 32) | lo;
     }
 }
 
@@ -1022,10 +1035,10 @@ __global__ __launch_bounds__(SB16R_THREADS) void sb16r_kernel(int n, int npad, i
     long long dacc[5] = {0, 0, 0, 0, 0}, dt0 = 0;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
-    const int grp = (wv >> 1) & 1, role = wv & 1, sw = 4 * grp + g;  // chasing waves 0 .. 3; the lane's sweep within a pass
-    const int zi = SB16R_Z + 64 * grp + 16 * g, dumpi = SB16R_DUMP + 64 * (wv & 3) + 16 * g;
-    int offD[16];
-    for (int i = 0; i < 16; ++i) offD[i] = i >= j ? 31 * j + i : 31 * i + j;
+    // chasing waves: 0, 1 = roles 0, 1 of sweeps 0..3; 2, 3 = roles 0, 1 of sweeps 4..7; 4, 5 = role 2 of sweeps 0..3, 4..7 (the waves with
+    // the long chains first, so that each has a SIMD where it is the only long one)
+    const int grp = wv < 4 ? (wv >> 1) & 1 : wv & 1, role = wv < 4 ? wv & 1 : 2, sw = 4 * grp + g;
+    const int zi = SB16R_Z + 64 * grp + 16 * g, dumpi = SB16R_DUMP + 64 * (wv % NCW4) + 16 * g;
     // ---- which channel; alone (ctl == nullptr) or member w of a ring of P workgroups
     int chn = blockIdx.x, w = 0, stride = 1;
     const unsigned long long *pollp = nullptr;
@@ -1071,7 +1084,7 @@ __global__ __launch_bounds__(SB16R_THREADS) void sb16r_kernel(int n, int npad, i
     const int npass = (n - 2 + NW2 - 1) / NW2;
     for (int ps = w; ps < npass; ps += stride) {
         const int s0 = ps * NW2;
-        int RP = s0, LP = s0 + 64;
+        int RP = s0, LP = s0 + 112;                       // columns leave the window left of RP; LP is the next one to be requested
         if (pollp && ps > 0) {                            // the first 128 columns of this pass, as the pass before left them
             if (tid == 0) {
                 const int need = s0 + 128 < n ? s0 + 128 : n;
@@ -1080,7 +1093,7 @@ __global__ __launch_bounds__(SB16R_THREADS) void sb16r_kernel(int n, int npad, i
             __syncthreads();
             asm volatile("buffer_inv sc1" ::: "memory");
         }
-        for (int idx = tid; idx < 64 * WROWS; idx += SB16R_THREADS) {
+        for (int idx = tid; idx < 112 * WROWS; idx += SB16R_THREADS) {
             const int c = s0 + (idx >> 5), d = idx & 31;
             Lw[((c & (WCOLS - 1)) << 5) + d] = c + d < n ? AB[(size_t)c * LD + d] : 0.0;
         }
@@ -1096,23 +1109,16 @@ __global__ __launch_bounds__(SB16R_THREADS) void sb16r_kernel(int n, int npad, i
         if (RPn > n) RPn = n; \
         if (RPn < RP) RPn = RP;
         if (wv == NCW4) {                                 // the last wave moves data and does nothing else
-            double qb[32];
-            unsigned long long pw = 0;                    // the partner's progress word as last seen
-            {
-                const int md = lane & 31, mh = lane >> 5;
-                const unsigned o0 = (unsigned)(LP + mh) * LD + md, omax = (unsigned)(n - 1) * LD;
-                for (int i = 0; i < 32; ++i) {            // unmasked value; the mask is applied at the LDS write
-                    unsigned o = o0 + 2 * LD * i;
-                    o = o < omax ? o : omax;
-                    qb[i] = AB[o];
-                }
-            }
+            unsigned long long pw = 0, ptmp = 0;          // the partner's progress word as last seen / as last requested
+            int RPold = RP;                               // RP one step ago
             __syncthreads();
 #define SB16R_MSTEP(PH) \
             if (t + PH < nsteps) { \
                 SB16R_RPN(t + PH) \
                 if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime(); \
-                mover_step<PH>(Lw, AB, qb, n, npad, LP, RP, RPn, ps, lane, pollp, pubp, pw, C, status); \
+                { int r4 = s0 + NW2 + B2 * ((t + PH - 4) - LAG * (NW2 - 1) - 1);      /* RPn of four steps ago */ \
+                  RPold = r4 > n ? n : (r4 < s0 ? s0 : r4); } \
+                mover_step<PH>(Lw, AB, n, npad, LP + 16 * PH, RP, RPn, RPold, ps, lane, pollp, pubp, pw, ptmp, C, status); \
                 if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[0] += t_ - dt0; dt0 = t_; } \
                 RP = RPn; \
                 lds_only_barrier(); \
@@ -1123,39 +1129,106 @@ __global__ __launch_bounds__(SB16R_THREADS) void sb16r_kernel(int n, int npad, i
                 LP += 64;
             }
 #undef SB16R_MSTEP
-            LP = s0 + 64;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            LP = s0 + 112;
         } else {
-            __syncthreads();
-            for (int t = 0; t < nsteps; ++t) {
-                SB16R_RPN(t)
-                RP = RPn;
-                if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime();
-                // row g of the wave: sweep s0 + sw, item t - 3 sw
-                const int s4 = s0 + sw, k4 = t - LAG * sw, r04 = s4 + 1 + B2 * k4;
-                const bool act = k4 >= 0 && s4 < n - 2 && r04 < n;
-                // a row whose diagonal / next tile wraps around the ring sends the wave through the general addresses
-                const bool slow = __builtin_amdgcn_ballot_w64(act && (r04 & (WCOLS - 1)) > WCOLS - 16) != 0;
-                const int xr = SB16R_XS + (((t & 1) * 8 + sw) << 5), xw = SB16R_XS + ((((t + 1) & 1) * 8 + sw) << 5);
-                if (role == 0) {
+            // Roles 0 and 1 fetch the tile of their NEXT item at the end of a step, behind their stores: both tiles are final by
+            // then (the lag of three leaves the diagonal tile of item k + 1 untouched from the step before item k runs, tools/proto_sbr.py;
+            // the one element of the next tile that the sweep ahead reaches later -- the first element of ITS next column -- already
+            // holds that column's beta, because the reflector is formed a step ahead here), so the loads of a step no longer stand
+            // between the barrier and its arithmetic.  Role 0 also reads back the (v, tau) it has just written (a wave's LDS
+            // operations are in order): its chain starts with the dot products.
+            const int s4 = s0 + sw;
+            const bool live = s4 < n - 2;
+            const int xs0 = SB16R_XS + (sw << 5);
+            if (role == 0) {
+                double bt[16], v[16], tq = 0.0;
+                int at[16];
+                for (int i = 0; i < 16; ++i) { bt[i] = 0.0; v[i] = 0.0; at[i] = 0; }
+                if (sw == 0 && live && s4 + 1 < n) {      // item (s0, 0) runs at step 0
+                    next_tile_addr<false>(s4 + 1, j, at);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { bt[i] = Lw[at[i] + 31 * i]; v[i] = Lw[xs0 + i]; }
+                    tq = Lw[xs0 + 16];
+                }
+                __syncthreads();
+                for (int t = 0; t < nsteps; ++t) {
+                    SB16R_RPN(t)
+                    RP = RPn;
+                    if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime();
+                    const int k4 = t - LAG * sw, r04 = s4 + 1 + B2 * k4;   // row g of the wave: sweep s0 + sw, item t - 3 sw
+                    const bool act = k4 >= 0 && live && r04 < n, actN = k4 >= -1 && live && r04 + B2 < n;
+                    const int xw = xs0 + (((t + 1) & 1) << 8);
                     if (act) {
-                        if (!slow) chase4_next<true>(Lw, r04, j, xr, xw);
-                        else chase4_next<false>(Lw, r04, j, xr, xw);
-                    } else if (k4 == -1 && s4 < n - 2) {  // the sweep starts in the next step: its reflector from the band column
+                        chase4_next(Lw, bt, v, tq, at, j, xw);
+                    } else if (k4 == -1 && live) {        // the sweep starts in the next step: its reflector from the band column
                         const int hx = ((s4 & (WCOLS - 1)) << 5) + 1 + j;
                         next_reflector(Lw, Lw[hx], j, xw, hx);
                     }
-                } else if (act) {
-                    const int c04 = k4 == 0 ? s4 : r04 - B2;
-                    if (!slow) chase4_diag<true>(Lw, r04, c04, k4 > 0, j, xr, zi, dumpi, offD);
-                    else chase4_diag<false>(Lw, r04, c04, k4 > 0, j, xr, zi, dumpi, offD);
+                    // for the next step: (v, tau) back from the slot, the next item's tile (general addresses for the whole wave
+                    // if the tile of one of its rows wraps around the ring: one step in eight)
+                    const bool wrapN = __builtin_amdgcn_ballot_w64(actN && ((r04 + B2) & (WCOLS - 1)) > WCOLS - 16) != 0;
+                    if (actN) {
+                        if (wrapN) next_tile_addr<false>(r04 + B2, j, at);
+                        else next_tile_addr<true>(r04 + B2, j, at);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) v[i] = Lw[xw + i];
+                        tq = Lw[xw + 16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) bt[i] = Lw[at[i] + 31 * i];
+                    }
+                    if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[2] += t_ - dt0; dt0 = t_; }
+                    // the loads above may still be in flight at the barrier; the stores before them may not (LDS operations of a
+                    // wave complete in order: with more than 15 loads behind the last store, 15 outstanding means the stores are done)
+                    if (__builtin_amdgcn_ballot_w64(actN) != 0) asm volatile("s_waitcnt lgkmcnt(15)\n\ts_barrier" ::: "memory");
+                    else lds_only_barrier();
+                    if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; }
                 }
-                if (diag) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[2] += t_ - dt0; dt0 = t_; }
-                lds_only_barrier();
-                if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; }
+            } else if (role == 1) {
+                double d[16];
+                int ad[16], offD[16];
+                for (int i = 0; i < 16; ++i) { d[i] = 0.0; ad[i] = 0; offD[i] = i >= j ? 31 * j + i : 31 * i + j; }
+                if (sw == 0 && live && s4 + 1 < n) {
+                    diag_tile_addr<false>(s4 + 1, j, offD, ad);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) d[i] = Lw[ad[i]];
+                }
+                __syncthreads();
+                for (int t = 0; t < nsteps; ++t) {
+                    SB16R_RPN(t)
+                    RP = RPn;
+                    if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime();
+                    const int k4 = t - LAG * sw, r04 = s4 + 1 + B2 * k4;
+                    const bool act = k4 >= 0 && live && r04 < n, actN = k4 >= -1 && live && r04 + B2 < n;
+                    if (act) chase4_diag(Lw, d, ad, j, xs0 + ((t & 1) << 8), zi, dumpi);
+                    const bool wrapN = __builtin_amdgcn_ballot_w64(actN && ((r04 + B2) & (WCOLS - 1)) > WCOLS - 16) != 0;
+                    if (actN) {
+                        if (wrapN) diag_tile_addr<false>(r04 + B2, j, offD, ad);
+                        else diag_tile_addr<true>(r04 + B2, j, offD, ad);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) d[i] = Lw[ad[i]];
+                    }
+                    if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[2] += t_ - dt0; dt0 = t_; }
+                    if (__builtin_amdgcn_ballot_w64(actN) != 0) asm volatile("s_waitcnt lgkmcnt(15)\n\ts_barrier" ::: "memory");
+                    else lds_only_barrier();
+                    if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; }
+                }
+            } else {
+                __syncthreads();
+                for (int t = 0; t < nsteps; ++t) {
+                    SB16R_RPN(t)
+                    RP = RPn;
+                    if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime();
+                    const int k4 = t - LAG * sw, r04 = s4 + 1 + B2 * k4;
+                    if (k4 > 0 && live && r04 < n) chase4_bulge(Lw, r04, r04 - B2, j, xs0 + ((t & 1) << 8), dumpi);
+                    if (diag) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[2] += t_ - dt0; dt0 = t_; }
+                    lds_only_barrier();
+                    if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; }
+                }
             }
         }
 #undef SB16R_RPN
-        LP += 64 * ((nsteps + 3) / 4);                    // blocks of 64 columns that entered the window
+        LP += 64 * ((nsteps + 3) / 4);                    // what was requested (far beyond n by the end of a pass)
         __syncthreads();
         int hi = LP < n ? LP : n;
         for (int idx = tid; idx < (hi - RP) * WROWS; idx += SB16R_THREADS) {
@@ -1255,8 +1328,11 @@ int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double 
         long long *dbuf = nullptr, h[45];
         BSP_HIP(hipMalloc(reinterpret_cast<void **>(&dbuf), sizeof(h)));
         BSP_HIP(hipMemsetAsync(dbuf, 0, sizeof(h), st));
-        if (rows) hipLaunchKernelGGL(sb16r_kernel, dim3(nblk), dim3(SB16R_THREADS), SB16R_LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf,
-                                     d_ctl, P, d_status, fab);
+        if (rows) {
+            hipLaunchKernelGGL(band_tail_zero_kernel, dim3(batch), dim3(256), 0, st, n, npad, d_AB);
+            hipLaunchKernelGGL(sb16r_kernel, dim3(nblk), dim3(SB16R_THREADS), SB16R_LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf,
+                               d_ctl, P, d_status, fab);
+        }
         else hipLaunchKernelGGL(sb16st_kernel, dim3(nblk), dim3(576), SB16_LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf, d_ctl, P,
                                 d_status, fab);
         const hipError_t le = hipGetLastError();
@@ -1273,8 +1349,11 @@ int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double 
         return BSP_OK;
     }
     KScope kt(KS_SB16ST, st);
-    if (rows) hipLaunchKernelGGL(sb16r_kernel, dim3(nblk), dim3(SB16R_THREADS), SB16R_LDS, st, n, npad, batch, d_AB, d_d, d_e,
-                                 (long long *)nullptr, d_ctl, P, d_status, fab);
+    if (rows) {
+        hipLaunchKernelGGL(band_tail_zero_kernel, dim3(batch), dim3(256), 0, st, n, npad, d_AB);
+        hipLaunchKernelGGL(sb16r_kernel, dim3(nblk), dim3(SB16R_THREADS), SB16R_LDS, st, n, npad, batch, d_AB, d_d, d_e,
+                           (long long *)nullptr, d_ctl, P, d_status, fab);
+    }
     else hipLaunchKernelGGL(sb16st_kernel, dim3(nblk), dim3(576), SB16_LDS, st, n, npad, batch, d_AB, d_d, d_e, (long long *)nullptr,
                             d_ctl, P, d_status, fab);
     BSP_HIP(hipGetLastError());

@@ -578,14 +578,24 @@ def test_sb2st_fallback_paths():
     note("sb2st default (two steps) vs 8: normwise %.2e" % (np.max(np.abs(E9 - E0)) / lam))
     assert np.max(np.abs(E9 - E0)) <= 1e-13 * lam
     for kw in [dict(sb2st_ring=8), dict(sb2st_ring=4), dict(sb2st_ring=2), dict(sb2st_ring=1), dict(sb2st_force_abort=1),
-               dict(sb2st_force_abort=2), dict(sb2sb_mfma=0)]:
+               dict(sb2st_force_abort=2), dict(sb2sb_mfma=0), dict(sb16_rows=0)]:
         with _Options(sb2st_version=9, **kw):
             E, info = prob.solve(0, 12)
         assert np.all(info == 0), kw
-        if "sb2sb_mfma" in kw:                 # the first, all-VALU block-chasing kernel: another order of the same sums
+        if "sb2sb_mfma" in kw or "sb16_rows" in kw:
+            # the first, all-VALU block-chasing kernel / the first layout of the band-16 chase (one tile spread over a wave):
+            # another order of the same sums
             assert np.max(np.abs(E - E9)) <= 1e-13 * lam
         else:
             assert np.array_equal(E, E9), (kw, np.max(np.abs(E - E9)) / lam)
+    # the first layout of the band-16 chase: its own rings and fallbacks bit for bit among themselves
+    with _Options(sb2st_version=9, sb16_rows=0):
+        E16, info = prob.solve(0, 12)
+    for kw in [dict(sb2st_ring=8), dict(sb2st_ring=1), dict(sb2st_force_abort=1)]:
+        with _Options(sb2st_version=9, sb16_rows=0, **kw):
+            E, info = prob.solve(0, 12)
+        assert np.all(info == 0), kw
+        assert np.array_equal(E, E16), (kw, np.max(np.abs(E - E16)) / lam)
     prob.close()
 
 

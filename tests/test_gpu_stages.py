@@ -291,6 +291,17 @@ def test_sb2st_two_step(n, npad, batch):
         err = np.max(np.abs(ev - ref)) / np.max(np.abs(ref))
         note("sb2st two-step n %d b%d eig err %.2e" % (n, b, err))
         assert err < 5e-14 * np.sqrt(n)
+    # the first layout of the second step (sb16_rows = 0: one tile spread over a wave), the cross-check of the default (a whole
+    # item per row of 16 lanes): the same reduction in another order of the sums
+    rows = capi.get_option("sb16_rows")
+    capi.set_option("sb2st_version", 9); capi.set_option("sb16_rows", 0)
+    try:
+        d0, e0 = capi.stage_sb2st(AB, n)
+    finally:
+        capi.set_option("sb2st_version", old); capi.set_option("sb16_rows", rows)
+    for b in range(batch):
+        ev, ev0 = eigvalsh_tridiagonal(d[b], e[b]), eigvalsh_tridiagonal(d0[b], e0[b])
+        assert np.max(np.abs(ev - ev0)) < 5e-14 * np.sqrt(n) * np.max(np.abs(ev0))
 
 
 @pytest.mark.parametrize("n,batch", [(5, 1), (300, 3), (1500, 2)])
