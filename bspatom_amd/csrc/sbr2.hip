@@ -305,30 +305,43 @@ __global__ __launch_bounds__(256) void sb2sb_mfma_kernel(int n, int npad, double
         pf[q] = AB[in ? (size_t)(r0 + c) * LD + (lane - c) : 0];
     }
     for (int q = 0; q < 4; ++q) xc[q] = rin ? xc[q] : 0.0;
-#pragma unroll
-    for (int i = 0; i < NB1; ++i) {
-        if (w == (i & 3)) {
-            const double x = xc[i >> 2];
-            const double nrm2 = wsum_dpp(lane > i ? x * x : 0.0);
-            const double alpha = rlane(x, i);
-            double tq = 0.0, scale = 0.0, beta = alpha;
-            if (nrm2 != 0.0) {
-                beta = -copysign(sqrt(alpha * alpha + nrm2), alpha);
-                tq = (beta - alpha) / beta;
-                scale = 1.0 / (alpha - beta);
-            }
-            V[lane * VLD + i] = lane < i ? 0.0 : (lane == i ? 1.0 : x * scale);
-            if (lane == 0) tau[i] = tq;
-            xc[i >> 2] = lane < i ? x : (lane == i ? beta : 0.0);
+    // Column i's reflector is formed by its owner (wave i & 3) and published through LDS; every wave then applies it to its own
+    // columns to the right.  With look-ahead: the owner of column i + 1 applies reflector i to that column FIRST and forms
+    // reflector i + 1 at once, while the other waves are still applying reflector i -- one barrier per column and the
+    // reflector's chain (norm, sqrt, two divisions) beside the updates instead of before them.  Every column sees the same
+    // operations in the same order as without look-ahead: the band comes out bit-identical.
+    auto make_reflector = [&](const int i) {               // by wave i & 3
+        const double x = xc[i >> 2];
+        const double nrm2 = wsum_dpp(lane > i ? x * x : 0.0);
+        const double alpha = rlane(x, i);
+        double tq = 0.0, scale = 0.0, beta = alpha;
+        if (nrm2 != 0.0) {
+            beta = -copysign(sqrt(alpha * alpha + nrm2), alpha);
+            tq = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
         }
-        lds_bar();
+        V[lane * VLD + i] = lane < i ? 0.0 : (lane == i ? 1.0 : x * scale);
+        if (lane == 0) tau[i] = tq;
+        xc[i >> 2] = lane < i ? x : (lane == i ? beta : 0.0);
+    };
+    if (w == 0) make_reflector(0);
+    lds_bar();
+#pragma unroll
+    for (int i = 0; i < NB1 - 1; ++i) {
         const double v = V[lane * VLD + i], tq = tau[i];
+        if (w == ((i + 1) & 3)) {
+            const int q1 = (i + 1) >> 2;
+            const double dot = wsum_dpp(v * xc[q1]);
+            xc[q1] -= tq * dot * v;
+            make_reflector(i + 1);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (w + 4 * q > i) {
+            if (w + 4 * q > i + 1) {
                 const double dot = wsum_dpp(v * xc[q]);
                 xc[q] -= tq * dot * v;
             }
+        lds_bar();
     }
     for (int q = 0; q < 4; ++q) {                          // R (and zeros) back to the band
         const int gc = pc0 + w + 4 * q;
@@ -984,8 +997,10 @@ template <int PH>
 __device__ __forceinline__ void mover_step(double *Lw, double *__restrict__ AB, const int n, const int npad, const int LP,
                                            const int RP, const int RPn, const int RPold, const int ps, const int lane,
                                            const unsigned long long *pollp, unsigned long long *pubp, unsigned long long &pw,
-                                           unsigned long long &ptmp, Sb16Ctl *C, int *status)
+                                           unsigned long long &ptmp, Sb16Ctl *C, int *status, const bool diag, long long (&dacc)[5])
 {
+    long long ts = diag ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#define MV_STAMP(q) if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[q] += t_ - ts; ts = t_; }
     const int md = lane & 31, mh = lane >> 5;                       // column-out lane: row md of columns 2 i + mh
     if (PH == 0 && pollp && ps > 0 && LP < n) {                    // the 64 columns requested in these four steps, as the pass before left them
         const int need = LP + 64 < n ? LP + 64 : n;
@@ -1005,6 +1020,7 @@ __device__ __forceinline__ void mover_step(double *Lw, double *__restrict__ AB, 
     // for it with a count that also covers the DMA just issued); a value read too early is an OLDER progress, which only
     // sends the check above into its polling loop.
     if (PH == 1 && pollp) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "+v"(ptmp) : "v"(pollp) : "memory");
+    MV_STAMP(1)                                                     // poll check and requests
     {
         const unsigned c0_ = (unsigned)(RP + mh), dumpo = (unsigned)npad * LD + 64 + lane;
 #pragma unroll
@@ -1014,10 +1030,13 @@ __device__ __forceinline__ void mover_step(double *Lw, double *__restrict__ AB, 
             AB[o] = Lw[((c & (WCOLS - 1)) << 5) + md];
         }
     }
+    MV_STAMP(0)                                                     // columns out: LDS reads, stores issued
     // All but the 48 youngest operations complete: the columns requested FOUR steps ago are in the window, and the stores of
     // that step have reached the L2 -- the columns left of RPold, progress for the member that runs the next pass.  (Two steps
     // were not enough: a step is shorter than half the latency of HBM and the wave waited for it every time.)
     asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    MV_STAMP(2)                                                     // the wait for the operations of four steps ago
+#undef MV_STAMP
     if (PH == 3 && pubp && lane == 0)
         __hip_atomic_store(pubp, ((unsigned long long)ps << 32) + (unsigned)RPold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (PH == 3 && pollp) {
@@ -1115,11 +1134,10 @@ __global__ __launch_bounds__(SB16R_THREADS) void sb16r_kernel(int n, int npad, i
 #define SB16R_MSTEP(PH) \
             if (t + PH < nsteps) { \
                 SB16R_RPN(t + PH) \
-                if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime(); \
                 { int r4 = s0 + NW2 + B2 * ((t + PH - 4) - LAG * (NW2 - 1) - 1);      /* RPn of four steps ago */ \
                   RPold = r4 > n ? n : (r4 < s0 ? s0 : r4); } \
-                mover_step<PH>(Lw, AB, n, npad, LP + 16 * PH, RP, RPn, RPold, ps, lane, pollp, pubp, pw, ptmp, C, status); \
-                if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[0] += t_ - dt0; dt0 = t_; } \
+                mover_step<PH>(Lw, AB, n, npad, LP + 16 * PH, RP, RPn, RPold, ps, lane, pollp, pubp, pw, ptmp, C, status, diag != nullptr, dacc); \
+                if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime(); \
                 RP = RPn; \
                 lds_only_barrier(); \
                 if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; } \
