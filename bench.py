@@ -389,13 +389,14 @@ def report(args, world, n, npad, main, ktimes, kstage):
     two_step = ver == 9 or (ver == 0 and n >= 512)
     if two_step:
         # Step 1, sb2sb_mfma_kernel: one launch per wavefront of independent chase items; an item reads and writes a 64 x 64 bulge
-        # tile, the lower triangle of a 64 x 64 diagonal tile and the next 64 x 64 tile.  Step 2, sb16st_kernel: ONE launch; every
-        # pass of 8 sweeps streams the remaining band (32 rows of 8 B per column) through an LDS window once: read + write.
+        # tile, the lower triangle of a 64 x 64 diagonal tile and the next 64 x 64 tile.  Step 2, sb16r_kernel (sb16st_kernel with
+        # BSP_SB16_ROWS=0): ONE launch; every pass of 8 sweeps streams the remaining band (32 rows of 8 B per column) through an
+        # LDS window once: read + write.
         items = sum(max(0, -(-(n - 16 * (s_ + 1)) // 64)) for s_ in range((n - 1) // 16))
         b1 = items * (2 * 64 * 64 * 8 + 2 * 2080 * 8 + 2 * 64 * 64 * 8) * nl
         b2 = sum(2 * 32 * 8 * (n - s0_) for s0_ in range(0, n - 2, 8)) * nl
         for sub, bytes_model, note in (("sb2sb_mfma", b1, "item latency at two workgroups per CU"),
-                                       ("sb16st", b2, "serial chase: VALU issue of one 16 x 16 item per wave and step")):
+                                       ("sb16", b2, "serial chase, one item per sweep and step: the LDS pipe and the latency of an item's dependent chains")):
             ms_sum, calls = kt(sub)
             if calls == 0:
                 continue
@@ -406,7 +407,7 @@ def report(args, world, n, npad, main, ktimes, kstage):
                          "achieved": bytes_model / (ms_sum * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": bytes_model / (ms_sum * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": tb, "traffic_source": pmc_file, "traffic_stale": pmc_stale, "limited_by": note})
-        kern.append({"kernel": "bulge chasing stage (sb2sb_mfma_kernel + sb16st_kernel)", "bound": "hbm", "launch_ms": sb_ms,
+        kern.append({"kernel": "bulge chasing stage (sb2sb_mfma_kernel + sb16r_kernel)", "bound": "hbm", "launch_ms": sb_ms,
                      "launch_ms_source": "HIP events around the stage, timed steps of this run", "bytes_min": sb_min,
                      "bytes_model": b1 + b2, "chase_items_sb2sb_per_channel": items,
                      "achieved": (b1 + b2) / (sb_ms * 1e-3) / 1e9 if sb_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

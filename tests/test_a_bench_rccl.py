@@ -37,7 +37,7 @@ def test_bench_under_torchrun_one_rank(scaling):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     # per-kernel entries: launch durations measured in this run (HIP events around every launch), frac = work / time
     ks = {k["kernel"].split("(")[0].split("<")[0].strip(): k for k in r["kernels"]}
-    for name in ("gemm2_kernel", "sb2sb_mfma_kernel", "sb16st_kernel"):
+    for name in ("gemm2_kernel", "sb2sb_mfma_kernel", "sb16r_kernel / sb16st_kernel"):
         assert name in ks, list(ks)
     for k in r["kernels"]:
         if "launches_per_step" in k:
