@@ -6,6 +6,6 @@ f=$(find /tmp/px -name '*kernel_stats.csv' | head -1)
 python3 -c "
 import csv
 for r in csv.DictReader(open('$f')):
-    if any(k in r['Name'] for k in ('gemm', 'tsmm', 'panel_qr', 'form_T', 'splitk')): print('%-60s calls %4s total %7.1f ms' % (r['Name'][5:65], r['Calls'], float(r['TotalDurationNs'])/1e6))
+    if any(k in r['Name'] for k in ('gemm', 'syr2k', 'tsmm', 'panel_qr', 'form_T', 'splitk')): print('%-60s calls %4s total %7.1f ms' % (r['Name'][5:65], r['Calls'], float(r['TotalDurationNs'])/1e6))
 "
 tail -1 /tmp/px.log | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('rydberg', d['rydberg_max_rel_err_n<=8'])"
