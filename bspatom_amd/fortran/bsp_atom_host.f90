@@ -11,6 +11,8 @@
 !  reference for KIND_PI >= 3 only (Enl(n0,l0) -> E_ini(n0) here; the loop bound n1_max -> n1_fin), and its
 !  T_fi(nf,il) is addressed with the channel l_fin it was allocated for; see DESIGN.md.
 !  The Gaussian / LG-beam branches that follow SOLVE_SYSTEM for KIND_PI >= 3 are not part of this host.
+!  With RANK / LOCAL_RANK / WORLD_SIZE in the environment (one process per GPU) the l-loop of SOLVE_SYSTEM
+!  (src/matrices.f90:242-248) is sharded over the ranks and rank 0 writes the outputs (KIND_PI = 0; see below).
       MODULE BSPATOM_C
       USE ISO_C_BINDING
       IMPLICIT NONE
@@ -122,6 +124,38 @@
 !     stdout echo of READ_INPUTS / SEL_LM (the numbers a run prints before MATRIX_SVT starts)
       INTEGER :: nshell(3), ntot_el, ifib, fa, fb, fc, nsel, il, im, la
       REAL(DP) :: rog(3,0:3), xn, ssum, Epump, Eprobe, kph
+!     l-channels sharded over the GPUs of a node: one process per GPU, started by any launcher that sets RANK, LOCAL_RANK and
+!     WORLD_SIZE (python -m torch.distributed.run --no-python, mpirun with a wrapper, a shell loop).  The channels are independent
+!     (matrices.f90:242-248), so the ranks exchange nothing while they solve; the spectra reach rank 0, which writes the
+!     reference's outputs, through files of a scratch directory (BSPATOM_XCHG, unique per run) -- the file boundary this
+!     program has anyway.  KIND_PI = 0 only, like the Python host's run_sharded.
+      INTEGER :: rank, world, lrank, devid, l0s, nls, nbase, nrem, rr, owner, r0s, nlr, ios, tries
+      LOGICAL :: have_wf, ex
+      CHARACTER(LEN=512) :: envv, xdir, fname
+      INTEGER(C_INT32_T), ALLOCATABLE :: infoall(:)
+
+      rank = 0; world = 1; lrank = 0
+      CALL GET_ENVIRONMENT_VARIABLE('WORLD_SIZE', envv, STATUS=ios)
+      IF( ios == 0 ) READ(envv,*,IOSTAT=ios) world
+      IF( world < 1 ) world = 1
+      IF( world > 1 ) THEN
+        CALL GET_ENVIRONMENT_VARIABLE('RANK', envv, STATUS=ios)
+        IF( ios == 0 ) READ(envv,*,IOSTAT=ios) rank
+        CALL GET_ENVIRONMENT_VARIABLE('LOCAL_RANK', envv, STATUS=ios)
+        IF( ios == 0 ) READ(envv,*,IOSTAT=ios) lrank
+        IF( rank < 0 .OR. rank >= world ) THEN
+          WRITE(0,*) 'bsp_atom_host: RANK outside 0 .. WORLD_SIZE - 1'
+          STOP 2
+        END IF
+!       every rank but the first is silent: rank 0's stdout is the program's
+        IF( rank > 0 ) OPEN( UNIT=6, FILE='/dev/null', ACTION='WRITE' )
+      END IF
+!     launchers forward stdin to one rank at most: the namelists can come from the file BSPATOM_INPUT names
+      CALL GET_ENVIRONMENT_VARIABLE('BSPATOM_INPUT', envv, STATUS=ios)
+      IF( ios == 0 .AND. LEN_TRIM(envv) > 0 ) OPEN( UNIT=5, FILE=TRIM(envv), ACTION='READ', STATUS='OLD' )
+      devid = lrank
+      CALL GET_ENVIRONMENT_VARIABLE('BSPATOM_DEVICE', envv, STATUS=ios)
+      IF( ios == 0 .AND. LEN_TRIM(envv) > 0 ) READ(envv,*,IOSTAT=ios) devid
 
       WRITE(6,'(A64)') 'PROGRAM TO CALCULATE ELECTRONIC STRUCTURE AND PI CROSS SECTIONS,'
       WRITE(6,'(A17,/)') '  USING B-SPLINES'
@@ -155,7 +189,11 @@
       inp%ra = ra; inp%rb = rb; inp%rmax = rmax
       inp%n0_ini = n0_ini; inp%l_ini = l_ini; inp%m_ini = m_ini; inp%l_fin = l_fin; inp%lmax = lmax
       inp%kind_pot = KIND_POT; inp%emax_fin = Emax_fin; inp%zatom = Zatom
-      rc = bspatom_problem_create(inp, 0_C_INT, prob)
+      IF( world > 1 .AND. KIND_PI /= 0 ) THEN
+        WRITE(0,*) 'bsp_atom_host: WORLD_SIZE > 1 shards the l-channels of a KIND_PI = 0 run; the other branches run on one GPU'
+        STOP 2
+      END IF
+      rc = bspatom_problem_create(inp, INT(devid,C_INT), prob)
       IF( rc /= 0 ) THEN
         WRITE(6,*) 'bsp_atom_host: bspatom_problem_create failed, code ', rc
         STOP 1
@@ -288,11 +326,87 @@
       WRITE(6,'(/,A34)') 'Calculating S, V, U and T Matrices'
 
       ALLOCATE( En(nfun*(lmax+1)), info(lmax+1), ci(nfun) )
-      rc = bspatom_solve(prob, 0_C_INT, INT(lmax+1,C_INT), En, info)
+      have_wf = .FALSE.
+      IF( world == 1 ) THEN
+        rc = bspatom_solve(prob, 0_C_INT, INT(lmax+1,C_INT), En, info)
+      ELSE
+!       this rank's block of channels, the static partition of bspatom_amd/parallel.py::channel_range
+        nbase = (lmax+1) / world; nrem = MOD(lmax+1, world)
+        nls = nbase; IF( rank < nrem ) nls = nbase + 1
+        l0s = rank*nbase + MIN(rank, nrem)
+        owner = 0
+        DO rr = 0, world-1
+          r0s = rr*nbase + MIN(rr, nrem); nlr = nbase; IF( rr < nrem ) nlr = nbase + 1
+          IF( l_ini >= r0s .AND. l_ini < r0s + nlr ) owner = rr
+        END DO
+        info = 0; rc = 0
+        IF( nls > 0 ) rc = bspatom_solve(prob, INT(l0s,C_INT), INT(nls,C_INT), En(l0s*nfun+1:), info(l0s+1:))
+      END IF
       IF( rc /= 0 ) THEN
         IF( rc == -3 ) WRITE(6,*) 'FATAL ERROR - BSPLVB'
-        WRITE(6,*) 'bsp_atom_host: bspatom_solve failed, code ', rc
+        WRITE(0,*) 'bsp_atom_host: bspatom_solve failed, code ', rc
         STOP 1
+      END IF
+      IF( world > 1 ) THEN
+        xdir = '.bspatom_xchg'
+        CALL GET_ENVIRONMENT_VARIABLE('BSPATOM_XCHG', envv, STATUS=ios)
+        IF( ios == 0 .AND. LEN_TRIM(envv) > 0 ) xdir = envv
+        CALL EXECUTE_COMMAND_LINE('mkdir -p '//TRIM(xdir))
+        npts = 10000
+        IF( rank == owner ) THEN                          ! the consumed eigenvector and its WRITE_WF table, by the rank that solved l_ini
+          ALLOCATE( r(0:npts), u(0:npts) )
+          rc = bspatom_eigvec(prob, INT(l_ini,C_INT), INT(n0_ini,C_INT), ci)
+          IF( rc == 0 ) rc = bspatom_write_wf(prob, ci, INT(npts,C_INT), r, u)
+          IF( rc /= 0 ) THEN
+            IF( rc == -3 ) WRITE(6,*) 'FATAL ERROR - BSPLVB'
+            WRITE(0,*) 'bsp_atom_host: eigenvector / WRITE_WF failed, code ', rc
+            STOP 1
+          END IF
+          have_wf = .TRUE.
+        END IF
+        IF( rank > 0 ) THEN
+!         written under another name and renamed: rank 0 never sees half a file
+          WRITE(fname,'(A,A,I0)') TRIM(xdir), '/spec.', rank
+          OPEN( UNIT=77, FILE=TRIM(fname)//'.tmp', ACCESS='STREAM', FORM='UNFORMATTED', ACTION='WRITE', STATUS='REPLACE' )
+          WRITE(77) INT(l0s,C_INT32_T), INT(nls,C_INT32_T)
+          IF( nls > 0 ) WRITE(77) info(l0s+1:l0s+nls), En(l0s*nfun+1:(l0s+nls)*nfun)
+          IF( have_wf ) THEN
+            WRITE(77) 1_C_INT32_T, r, u
+          ELSE
+            WRITE(77) 0_C_INT32_T
+          END IF
+          CLOSE(77)
+          CALL EXECUTE_COMMAND_LINE('mv '//TRIM(fname)//'.tmp '//TRIM(fname))
+          CALL bspatom_problem_destroy(prob)
+          STOP
+        END IF
+        ALLOCATE( infoall(2) )
+        DO rr = 1, world-1                                ! rank 0 collects
+          WRITE(fname,'(A,A,I0)') TRIM(xdir), '/spec.', rr
+          tries = 0
+          DO
+            INQUIRE( FILE=TRIM(fname), EXIST=ex )
+            IF( ex ) EXIT
+            tries = tries + 1
+            IF( tries > 36000 ) THEN                      ! half an hour
+              WRITE(0,*) 'bsp_atom_host: no spectra from rank ', rr, ' in ', TRIM(xdir)
+              STOP 3
+            END IF
+            CALL EXECUTE_COMMAND_LINE('sleep 0.05')
+          END DO
+          OPEN( UNIT=77, FILE=TRIM(fname), ACCESS='STREAM', FORM='UNFORMATTED', ACTION='READ', STATUS='OLD' )
+          READ(77) infoall(1), infoall(2)
+          r0s = infoall(1); nlr = infoall(2)
+          IF( nlr > 0 ) READ(77) info(r0s+1:r0s+nlr), En(r0s*nfun+1:(r0s+nlr)*nfun)
+          READ(77) infoall(1)
+          IF( infoall(1) == 1 ) THEN
+            ALLOCATE( r(0:npts), u(0:npts) )
+            READ(77) r, u
+            have_wf = .TRUE.
+          END IF
+          CLOSE(77, STATUS='DELETE')
+        END DO
+        DEALLOCATE( infoall )
       END IF
       WRITE(6,'(A19,/)') 'Matrices Calculated'
 
@@ -316,10 +430,13 @@
         END DO
         IF( l == l_ini ) THEN
           WRITE(6,'(/,A29,/)') 'Writing down Initial State WF'
-          rc = bspatom_eigvec(prob, INT(l,C_INT), INT(n0_ini,C_INT), ci)
           npts = 10000
-          ALLOCATE( r(0:npts), u(0:npts) )
-          IF( rc == 0 ) rc = bspatom_write_wf(prob, ci, INT(npts,C_INT), r, u)
+          rc = 0
+          IF( .NOT. have_wf ) THEN
+            rc = bspatom_eigvec(prob, INT(l,C_INT), INT(n0_ini,C_INT), ci)
+            ALLOCATE( r(0:npts), u(0:npts) )
+            IF( rc == 0 ) rc = bspatom_write_wf(prob, ci, INT(npts,C_INT), r, u)
+          END IF
           IF( rc == -3 ) THEN
             WRITE(6,*) 'FATAL ERROR - BSPLVB'
             STOP

@@ -231,6 +231,42 @@ def test_fortran_host_drop_in(tmp_path, name):
     assert [int(a.split()[0]) for a in mine] == [int(b.split()[0]) for b in ref]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,l_ini", [(2, 0), (2, 3), (3, 4)])
+def test_fortran_host_sharded(tmp_path, world, l_ini):
+    """bsp_atom_host.x as one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE in the environment, as a launcher sets them): every
+    rank solves its block of l-channels (the loop of matrices.f90:242-248, sharded), the spectra and the consumed eigenvector's
+    table reach rank 0 through the files of BSPATOM_XCHG, and rank 0's stdout, Enl.dat and wf_n0.dat are byte for byte what the
+    single process writes -- also when another rank owns l_ini.  The test box has one GPU: every rank is sent to device 0."""
+    import subprocess
+    exe = os.path.join(ROOT, "bspatom_amd", "bsp_atom_host.x")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran host not built (no flang)")
+    text = open(golden_input("simfues")).read().replace("l_ini=0", "l_ini=%d" % l_ini)
+    assert "l_ini=%d" % l_ini in text
+    inp = tmp_path / "in.inp"; inp.write_text(text)
+    one = tmp_path / "one"; one.mkdir()
+    with open(inp) as fin:
+        p1 = subprocess.run([exe], stdin=fin, cwd=one, capture_output=True, text=True, timeout=300)
+    assert p1.returncode == 0 and "Program Finished!" in p1.stdout, p1.stdout + p1.stderr
+    many = tmp_path / "many"; many.mkdir()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), BSPATOM_DEVICE="0",
+                   BSPATOM_INPUT=str(inp), BSPATOM_XCHG=str(tmp_path / "xchg"))
+        procs.append(subprocess.Popen([exe], stdin=subprocess.DEVNULL, cwd=many, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [q.communicate(timeout=600) for q in procs]
+    for r, q in enumerate(procs):
+        assert q.returncode == 0, (r, outs[r])
+        if r > 0:
+            assert outs[r][0] == ""                        # only rank 0 speaks
+    assert outs[0][0] == p1.stdout
+    assert open(many / "Enl.dat").read() == open(one / "Enl.dat").read()
+    assert open(many / "wf_n0.dat").read() == open(one / "wf_n0.dat").read()
+    assert not list((tmp_path / "xchg").glob("spec.*"))    # consumed
+
+
 def test_python_host_outputs(tmp_path):
     from bspatom_amd import host
     g = load_golden("c1_lin")
