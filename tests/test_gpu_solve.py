@@ -267,6 +267,30 @@ def test_fortran_host_sharded(tmp_path, world, l_ini):
     assert not list((tmp_path / "xchg").glob("spec.*"))    # consumed
 
 
+@pytest.mark.gpu
+def test_fortran_host_under_torchrun(tmp_path):
+    """The documented launch line: `python -m torch.distributed.run --no-python --nproc-per-node 2 bsp_atom_host.x`
+    (both ranks on the test box's one GPU): outputs byte for byte those of the single process."""
+    import subprocess, sys
+    exe = os.path.join(ROOT, "bspatom_amd", "bsp_atom_host.x")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran host not built (no flang)")
+    inp = golden_input("simfues")
+    one = tmp_path / "one"; one.mkdir()
+    with open(inp) as fin:
+        p1 = subprocess.run([exe], stdin=fin, cwd=one, capture_output=True, text=True, timeout=300)
+    assert p1.returncode == 0, p1.stdout + p1.stderr
+    many = tmp_path / "many"; many.mkdir()
+    env = dict(os.environ, BSPATOM_DEVICE="0", BSPATOM_INPUT=os.path.abspath(inp), BSPATOM_XCHG=str(tmp_path / "xchg"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--no-python", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29900 + os.getpid() % 40), exe]
+    p = subprocess.run(cmd, cwd=many, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert open(many / "Enl.dat").read() == open(one / "Enl.dat").read()
+    assert open(many / "wf_n0.dat").read() == open(one / "wf_n0.dat").read()
+    assert p1.stdout in p.stdout                            # the launcher may add lines of its own around rank 0's
+
+
 def test_python_host_outputs(tmp_path):
     from bspatom_amd import host
     g = load_golden("c1_lin")
