@@ -21,14 +21,23 @@ namespace bsp {
 // these -- tools/microbench/mfma4_probe.hip -- and which a register-only loop runs at 72 TFLOP/s against 36-48 for
 // 16x16x4 -- tools/microbench/mfma_f64_peak.hip -- was tried: 20 instead of 8 LDS reads per step, and the kernels
 // came out 2-5 % SLOWER; they are not bound by the matrix pipe.)
+// LDS image of a staged tile: row k holds its columns permuted inside every aligned group of 16, column x at x ^ lds_swz(k).
+// The row stride (BX + 16 doubles) puts rows k and k + 2 on the same banks; an operand that is contiguous along k in memory is
+// stored with eight lanes of a 16-lane group on rows k, k + 2, .., k + 14 of ONE column -- an eight-way bank conflict per
+// ds_write_b64 without the permutation (counters, profiles/r03_lds_util.json: 63 % of symm's LDS-array cycles and 70 % of
+// gemm_kernel<64,64>'s were conflict cycles), none with it: the eight rows land on eight different even offsets.  A fragment
+// read takes the 16 columns of a group in permuted order (the same banks); pairs of columns stay pairs (the offset is even).
+__device__ __forceinline__ int lds_swz(int k) { return ((k >> 1) & 7) << 1; }
+
 template <int TM, int TN>
-__device__ __forceinline__ void mfma_step(const double *Arow, const double *Brow, int lane, double4_t (&acc)[TM][TN])
+__device__ __forceinline__ void mfma_step(const double *Arow, const double *Brow, int lane, int kr, double4_t (&acc)[TM][TN])
 {
     double a[TM], b[TN];
+    const int c = (lane & 15) ^ lds_swz(kr);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a[i] = Arow[i * 16 + (lane & 15)];
+    for (int i = 0; i < TM; ++i) a[i] = Arow[i * 16 + c];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b[j] = Brow[j * 16 + (lane & 15)];
+    for (int j = 0; j < TN; ++j) b[j] = Brow[j * 16 + c];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc g)
                 const int gm = m0 + mm, gk = k0 + kk;
                 const bool ok = (gk < Kend) && (gm + 1 < g.M);
                 const double2 v = *reinterpret_cast<const double2 *>(A + (ok ? ((long)gm + (long)gk * g.sAk) : 0));
-                *reinterpret_cast<double2 *>(&As[kk * LDA + mm]) = ok ? v : make_double2(0.0, 0.0);
+                *reinterpret_cast<double2 *>(&As[kk * LDA + (mm ^ lds_swz(kk))]) = ok ? v : make_double2(0.0, 0.0);
             }
         } else {           // contiguous along k: double2 along k
 #pragma unroll
@@ -89,8 +98,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc g)
                 const int gm = m0 + mm, gk = k0 + kk;
                 const bool ok = (gm < g.M) && (gk + 1 < Kend);
                 const double2 v = *reinterpret_cast<const double2 *>(A + (ok ? ((long)gm * g.sAm + (long)gk) : 0));
-                As[kk * LDA + mm] = ok ? v.x : 0.0;
-                As[(kk + 1) * LDA + mm] = ok ? v.y : 0.0;
+                As[kk * LDA + (mm ^ lds_swz(kk))] = ok ? v.x : 0.0;
+                As[(kk + 1) * LDA + (mm ^ lds_swz(kk))] = ok ? v.y : 0.0;         // kk is even: the same offset
             }
         }
         // ---- stage B tile (BK x BN) ----
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc g)
                 const int gn = n0 + nn, gk = k0 + kk;
                 const bool ok = (gk < Kend) && (gn + 1 < g.N);
                 const double2 v = *reinterpret_cast<const double2 *>(B + (ok ? ((long)gn + (long)gk * g.sBk) : 0));
-                *reinterpret_cast<double2 *>(&Bs[kk * LDB + nn]) = ok ? v : make_double2(0.0, 0.0);
+                *reinterpret_cast<double2 *>(&Bs[kk * LDB + (nn ^ lds_swz(kk))]) = ok ? v : make_double2(0.0, 0.0);
             }
         } else {           // contiguous along k
 #pragma unroll
@@ -112,15 +121,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc g)
                 const int gn = n0 + nn, gk = k0 + kk;
                 const bool ok = (gn < g.N) && (gk + 1 < Kend);
                 const double2 v = *reinterpret_cast<const double2 *>(B + (ok ? ((long)gn * g.sBn + (long)gk) : 0));
-                Bs[kk * LDB + nn] = ok ? v.x : 0.0;
-                Bs[(kk + 1) * LDB + nn] = ok ? v.y : 0.0;
+                Bs[kk * LDB + (nn ^ lds_swz(kk))] = ok ? v.x : 0.0;
+                Bs[(kk + 1) * LDB + (nn ^ lds_swz(kk))] = ok ? v.y : 0.0;
             }
         }
         __syncthreads();
 #pragma unroll
         for (int k4 = 0; k4 < BK / 4; ++k4) {
             const int kr = k4 * 4 + (lane >> 4);
-            mfma_step<TM, TN>(&As[kr * LDA + wm * (BM / WM)], &Bs[kr * LDB + wn * (BN / WN)], lane, acc);
+            mfma_step<TM, TN>(&As[kr * LDA + wm * (BM / WM)], &Bs[kr * LDB + wn * (BN / WN)], lane, kr, acc);
         }
         __syncthreads();
     }
@@ -350,11 +359,11 @@ __device__ __forceinline__ void tile_store(const double2 (&r)[BK * BX / 512], do
         const int idx = tid + it * 256;
         if (LAY == 0) {
             const int kk = idx / (BX / 2), xx = (idx % (BX / 2)) * 2;
-            *reinterpret_cast<double2 *>(&S[kk * LD + xx]) = r[it];
+            *reinterpret_cast<double2 *>(&S[kk * LD + (xx ^ lds_swz(kk))]) = r[it];
         } else {
-            const int xx = idx / (BK / 2), kk = (idx % (BK / 2)) * 2;
-            S[kk * LD + xx] = r[it].x;
-            S[(kk + 1) * LD + xx] = r[it].y;
+            const int xx = idx / (BK / 2), kk = (idx % (BK / 2)) * 2;        // kk is even: rows kk and kk + 1 share the offset
+            S[kk * LD + (xx ^ lds_swz(kk))] = r[it].x;
+            S[(kk + 1) * LD + (xx ^ lds_swz(kk))] = r[it].y;
         }
     }
 }
@@ -557,7 +566,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }                                                                                                \
             _Pragma("unroll") for (int k4 = 0; k4 < BK / 4; ++k4) {                                          \
                 const int kr = k4 * 4 + (lane >> 4);                                                         \
-                mfma_step<TM, TN>(&As[cur][kr * LDA + wm * (BM / WM)], &Bs[cur][kr * LDB + wn * (BN / WN)], lane, acc); \
+                mfma_step<TM, TN>(&As[cur][kr * LDA + wm * (BM / WM)], &Bs[cur][kr * LDB + wn * (BN / WN)], lane, kr, acc); \
             }                                                                                                \
             if ((t_) + 1 < nk) {                                                                             \
                 tile_store<BM, ALAY>(S1a, As[cur ^ 1], tid);                                                 \
@@ -586,7 +595,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     #pragma unroll
             for (int k4 = 0; k4 < BK / 4; ++k4) {
                 const int kr = k4 * 4 + (lane >> 4);
-                mfma_step<TM, TN>(&As[cur][kr * LDA + wm * (BM / WM)], &Bs[cur][kr * LDB + wn * (BN / WN)], lane, acc);
+                mfma_step<TM, TN>(&As[cur][kr * LDA + wm * (BM / WM)], &Bs[cur][kr * LDB + wn * (BN / WN)], lane, kr, acc);
             }
             G2_STAMP(3)                                          // MFMAs of this k-tile (and issue of the next loads)
             if (t + 1 < nk) {
