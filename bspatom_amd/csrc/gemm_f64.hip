@@ -29,11 +29,12 @@ namespace bsp {
 // read takes the 16 columns of a group in permuted order (the same banks); pairs of columns stay pairs (the offset is even).
 __device__ __forceinline__ int lds_swz(int k) { return ((k >> 1) & 7) << 1; }
 
-template <int TM, int TN>
+// SW = false: no operand of the kernel is staged with the transposed store (the rank-128 update): plain rows
+template <int TM, int TN, bool SW = true>
 __device__ __forceinline__ void mfma_step(const double *Arow, const double *Brow, int lane, int kr, double4_t (&acc)[TM][TN])
 {
     double a[TM], b[TN];
-    const int c = (lane & 15) ^ lds_swz(kr);
+    const int c = SW ? (lane & 15) ^ lds_swz(kr) : (lane & 15);
 #pragma unroll
     for (int i = 0; i < TM; ++i) a[i] = Arow[i * 16 + c];
 #pragma unroll
@@ -350,7 +351,7 @@ __device__ __forceinline__ void tile_load(double2 (&r)[BK * BX / 512], const dou
     }
 }
 
-template <int BX, int LAY>
+template <int BX, int LAY, bool SW = true>
 __device__ __forceinline__ void tile_store(const double2 (&r)[BK * BX / 512], double *S, int tid)
 {
     constexpr int LD = BX + 16;
@@ -359,7 +360,7 @@ __device__ __forceinline__ void tile_store(const double2 (&r)[BK * BX / 512], do
         const int idx = tid + it * 256;
         if (LAY == 0) {
             const int kk = idx / (BX / 2), xx = (idx % (BX / 2)) * 2;
-            *reinterpret_cast<double2 *>(&S[kk * LD + (xx ^ lds_swz(kk))]) = r[it];
+            *reinterpret_cast<double2 *>(&S[kk * LD + (SW ? xx ^ lds_swz(kk) : xx)]) = r[it];
         } else {
             const int xx = idx / (BK / 2), kk = (idx % (BK / 2)) * 2;        // kk is even: rows kk and kk + 1 share the offset
             S[kk * LD + (xx ^ lds_swz(kk))] = r[it].x;
@@ -415,6 +416,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int WM = 2, WN = 2;
     constexpr int LDA = BM + 16, LDB = BN + 16;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr bool SW = (MODE != 1);                       // MODE 1 stages both operands along x: no transposed store, plain rows
     __shared__ double As[2][BK * LDA];
     __shared__ double Bs[2][BK * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -494,8 +496,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #define G2_STORE_B(k0_, S_, rb)                                              \
     {                                                                        \
-        if (MODE == 2 && (k0_) >= ksw) tile_store<BN, 1>(rb, S_, tid);       \
-        else tile_store<BN, BLAY>(rb, S_, tid);                              \
+        if (MODE == 2 && (k0_) >= ksw) tile_store<BN, 1, SW>(rb, S_, tid);   \
+        else tile_store<BN, BLAY, SW>(rb, S_, tid);                          \
     }
     if (MODE == 1) {
         tile_load<BM, ALAY>(ra, A, g.sAm, g.sAk, m0, 0, g.M, g.K, tid);
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     G2_STAMP(0)                                              // C, first A/B tiles: loads issued
     if (DIAGG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); G2_STAMP(1) }   // ... and arrived
-    tile_store<BM, ALAY>(ra, As[0], tid);
+    tile_store<BM, ALAY, SW>(ra, As[0], tid);
     G2_STORE_B(0, Bs[0], rb)
     lds_barrier2();
     G2_STAMP(2)
@@ -566,10 +568,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }                                                                                                \
             _Pragma("unroll") for (int k4 = 0; k4 < BK / 4; ++k4) {                                          \
                 const int kr = k4 * 4 + (lane >> 4);                                                         \
-                mfma_step<TM, TN>(&As[cur][kr * LDA + wm * (BM / WM)], &Bs[cur][kr * LDB + wn * (BN / WN)], lane, kr, acc); \
+                mfma_step<TM, TN, SW>(&As[cur][kr * LDA + wm * (BM / WM)], &Bs[cur][kr * LDB + wn * (BN / WN)], lane, kr, acc); \
             }                                                                                                \
             if ((t_) + 1 < nk) {                                                                             \
-                tile_store<BM, ALAY>(S1a, As[cur ^ 1], tid);                                                 \
+                tile_store<BM, ALAY, SW>(S1a, As[cur ^ 1], tid);                                                 \
                 G2_STORE_B(((t_) + 1) * BK, Bs[cur ^ 1], S1b)                                                \
             }                                                                                                \
             lds_barrier2();                                                                                  \
@@ -595,12 +597,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     #pragma unroll
             for (int k4 = 0; k4 < BK / 4; ++k4) {
                 const int kr = k4 * 4 + (lane >> 4);
-                mfma_step<TM, TN>(&As[cur][kr * LDA + wm * (BM / WM)], &Bs[cur][kr * LDB + wn * (BN / WN)], lane, kr, acc);
+                mfma_step<TM, TN, SW>(&As[cur][kr * LDA + wm * (BM / WM)], &Bs[cur][kr * LDB + wn * (BN / WN)], lane, kr, acc);
             }
             G2_STAMP(3)                                          // MFMAs of this k-tile (and issue of the next loads)
             if (t + 1 < nk) {
                 if (DIAGG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); G2_STAMP(4) }   // wait for the next tile
-                tile_store<BM, ALAY>(ra, As[cur ^ 1], tid);
+                tile_store<BM, ALAY, SW>(ra, As[cur ^ 1], tid);
                 G2_STORE_B((t + 1) * BK, Bs[cur ^ 1], rb)
             }
             lds_barrier2();
