@@ -348,7 +348,11 @@
         STOP 1
       END IF
       IF( world > 1 ) THEN
+!       default: a directory under the working directory that carries the launcher's rendezvous port (the same for all
+!       ranks of a run, different for runs that overlap in time)
         xdir = '.bspatom_xchg'
+        CALL GET_ENVIRONMENT_VARIABLE('MASTER_PORT', envv, STATUS=ios)
+        IF( ios == 0 .AND. LEN_TRIM(envv) > 0 ) xdir = '.bspatom_xchg.'//TRIM(envv)
         CALL GET_ENVIRONMENT_VARIABLE('BSPATOM_XCHG', envv, STATUS=ios)
         IF( ios == 0 .AND. LEN_TRIM(envv) > 0 ) xdir = envv
         CALL EXECUTE_COMMAND_LINE('mkdir -p '//TRIM(xdir))

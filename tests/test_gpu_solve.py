@@ -281,7 +281,8 @@ def test_fortran_host_under_torchrun(tmp_path):
         p1 = subprocess.run([exe], stdin=fin, cwd=one, capture_output=True, text=True, timeout=300)
     assert p1.returncode == 0, p1.stdout + p1.stderr
     many = tmp_path / "many"; many.mkdir()
-    env = dict(os.environ, BSPATOM_DEVICE="0", BSPATOM_INPUT=os.path.abspath(inp), BSPATOM_XCHG=str(tmp_path / "xchg"))
+    env = dict(os.environ, BSPATOM_DEVICE="0", BSPATOM_INPUT=os.path.abspath(inp))     # exchange directory: the default, .bspatom_xchg.<port>
+    env.pop("BSPATOM_XCHG", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--no-python", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(29900 + os.getpid() % 40), exe]
     p = subprocess.run(cmd, cwd=many, env=env, capture_output=True, text=True, timeout=900)
