@@ -55,7 +55,6 @@ struct Options {
     int bisect_tail = 1;         // BSP_BISECT_TAIL: 0 = lock-step bisection to the end (no multisection tail), for A/B timing
     int no_eigvec_prefetch = 0;
     int sb2sb_mfma = 1;          // 1: block-chasing item on the matrix cores (sbr2.hip); 0: the first, all-VALU kernel (cross-check)
-    int syr2k3 = 0;              // BSP_SYR2K3: 1 = the rank-128 update with three workgroups per CU (LDS-DMA staging, K-steps of 8; gemm_f64.hip)
     int sb16_rows = 1;           // BSP_SB16_ROWS: 1 = band 16 -> 1 with a whole chase item per DPP row, four sweeps per wave (sbr2.hip); 0 = the
                                  // first layout (one tile spread over a wave), kept as the cross-check
     int poison_c = 0;            // test hook: fill the dense C buffer with NaN bit patterns before every solve (nothing outside the

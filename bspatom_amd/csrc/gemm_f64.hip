@@ -638,146 +638,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-// ================================================================================================
-// The rank-128 update with THREE workgroups per CU (BSP_SYR2K3=1, experimental).  gemm2_kernel<128,128,.,.,1> spends a third of a
-// workgroup's life waiting for its C tile and relies on the second workgroup of the CU to fill the gap; a third one needs
-// <= 168 registers per lane and <= 53 KB of LDS: K-steps of 8 instead of 16, LDS rows without padding (32 KB for both operands,
-// double-buffered), and the A/B tiles staged by LDS-DMA (no staging registers).  A row of the LDS image is one 1-KB DMA: lane L
-// delivers the column pair L ^ 8 (k & 1), i.e. odd rows hold their columns with bit 4 flipped, so that the two rows a 32-lane
-// group of a fragment read touches lie on different bank halves although every row starts on bank 0.  Same products in the
-// same order as gemm2_kernel: bit-identical.
-// ================================================================================================
-constexpr int BK3 = 8;
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void syr2k3_kernel(GemmDesc g)
-{
-    constexpr int BM = 128, BN = 128, WM = 2, WN = 2, TM = 4, TN = 4;
-    __shared__ __attribute__((aligned(16))) double As[2][BK3 * BM];
-    __shared__ __attribute__((aligned(16))) double Bs[2][BK3 * BN];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    int bx, by, bz;
-    {                                                               // the tile of this workgroup: as gemm2_kernel, MODE 1
-        const int id = blockIdx.x, xcd = id & 7, q = id >> 3;
-        const int nb = (g.N + BN - 1) / BN, T = g.lower_only;
-        const int zi = q / T;
-        int t = __builtin_amdgcn_readfirstlane(q - zi * T + g.toff);
-        bz = xcd + 8 * zi;
-        if (bz >= g.batch) return;
-        const int ylo = g.yoff, part1 = (g.yoff == 0 && g.nsb > 0 && g.sbpre[g.nsb - 1] == nb);
-        int sb = 0;
-        while (t >= g.sbpre[sb]) ++sb;
-        if (sb) t -= g.sbpre[sb - 1];
-        const int sxy = g.sbxy[sb];
-        const int sy0 = 8 * (sxy >> 8);
-        bx = 8 * (sxy & 255);
-        for (;;) {
-            const int yhi = part1 ? 0 : ((bx + 1 < nb - 1) ? bx + 1 : nb - 1);
-            const int lo = (ylo > sy0) ? ylo : sy0, hi = (yhi < sy0 + 7) ? yhi : sy0 + 7;
-            const int c = hi - lo + 1;
-            if (c > 0 && t < c) { by = lo + t; break; }
-            if (c > 0) t -= c;
-            ++bx;
-        }
-    }
-    const int m0 = by * BM, n0 = bx * BN;
-    const char *A = reinterpret_cast<const char *>(g.A + (long)bz * g.bA);
-    const char *B = reinterpret_cast<const char *>(g.B + (long)bz * g.bB);
-    double *C = g.C + (long)bz * g.bC;
-    const double alpha = g.alpha, sc = g.beta / g.alpha;
-    // DMA sources of this lane: rows k = wave, wave + 4 of a K-step; columns 2 x, 2 x + 1 with x = lane ^ 8 (k & 1); rows beyond
-    // the operand are clamped (they feed output rows that are never stored)
-    unsigned offA[2], offB[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int k = wave + 4 * q, x = lane ^ (8 * (k & 1));
-        int ga = m0 + 2 * x, gb = n0 + 2 * x;
-        ga = ga + 1 < g.M ? ga : g.M - 2;
-        gb = gb + 1 < g.N ? gb : g.N - 2;
-        offA[q] = (unsigned)(((long)ga + (long)k * g.sAk) * 8);
-        offB[q] = (unsigned)(((long)gb + (long)k * g.sBk) * 8);
-    }
-    const long ksA = g.sAk * 8 * BK3, ksB = g.sBk * 8 * BK3;          // bytes per K-step
-    auto stage = [&](const int t, const int buf) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int k = wave + 4 * q;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A + t * ksA + offA[q]),
-                                             (__attribute__((address_space(3))) void *)&As[buf][k * BM], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(B + t * ksB + offB[q]),
-                                             (__attribute__((address_space(3))) void *)&Bs[buf][k * BN], 16, 0, 0);
-        }
-    };
-    stage(0, 0);
-    double4_t acc[TM][TN];
-    const int wr0 = m0 + wm * (BM / WM), wc0 = n0 + wn * (BN / WN);
-    const bool inside = (wr0 + BM / WM <= g.M) && (wc0 + BN / WN <= g.N);
-    double *Cl = C + (long)(wr0 + (lane >> 4)) * g.sCm + (long)(wc0 + (lane & 15));
-    if (inside) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double *pr = Cl + (long)(16 * i + 4 * r) * g.sCm;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j][r] = sc * __builtin_nontemporal_load(&pr[16 * j]);
-            }
-    } else {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gi = wr0 + i * 16 + (lane >> 4) + 4 * r, gj = wc0 + j * 16 + (lane & 15);
-                    const bool ok = (gi < g.M && gj < g.N);
-                    const double v = C[ok ? ((long)gi * g.sCm + (long)gj) : 0];
-                    acc[i][j][r] = ok ? sc * v : 0.0;
-                }
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll 1
-    for (int t = 0; t < 128 / BK3; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < 128 / BK3) stage(t + 1, cur ^ 1);               // the buffer step t - 1 read: every wave has passed that step's barrier
-#pragma unroll
-        for (int k4 = 0; k4 < BK3 / 4; ++k4) {
-            const int kr = k4 * 4 + (lane >> 4), fl = kr & 1;      // odd rows: bit 4 of the column flipped
-            const double *Ar = &As[cur][kr * BM + wm * (BM / WM) + (lane & 15)], *Br = &Bs[cur][kr * BN + wn * (BN / WN) + (lane & 15)];
-            double a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = Ar[(i ^ fl) * 16];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Br[(j ^ fl) * 16];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        // the DMA of the next step has landed (this wave's part: the counter; the others': the barrier), and every wave is done with cur
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    if (inside) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double *pr = Cl + (long)(16 * i + 4 * r) * g.sCm;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) __builtin_nontemporal_store(alpha * acc[i][j][r], &pr[16 * j]);
-            }
-    } else {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gi = wr0 + i * 16 + (lane >> 4) + 4 * r, gj = wc0 + j * 16 + (lane & 15);
-                    if (gi < g.M && gj < g.N) C[(long)gi * g.sCm + (long)gj] = alpha * acc[i][j][r];
-                }
-    }
-}
-
 // A22 (m x m, column-major, ld) -= P Q^T with P = buf[:, 0:128], Q = buf[:, 64:192] (ldb rows apart),
 // only tiles with column block <= row block + 1.
 int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const double *buf, long ldb, long bsBuf, int seg, int nseg,
@@ -820,11 +680,6 @@ int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const doub
     dim3 grid((unsigned)(8 * ((batch + 7) / 8) * T), 1, 1);
     KScope kt(KS_SYR2K, st);
     const int gd = opts().gemm_diag;
-    if (opts().syr2k3 && !gd && g.K == 128) {
-        hipLaunchKernelGGL(syr2k3_kernel, grid, dim3(256), 0, st, g);
-        BSP_HIP(hipGetLastError());
-        return BSP_OK;
-    }
     if (gd && part == 2 && m >= 3900) {
         long long z[8] = {0};
         BSP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm2_diag), z, sizeof(z)));
