@@ -34,7 +34,7 @@ class Sizes(C.Structure):
 EXPORTS = ["bspatom_input_defaults", "bspatom_device_count", "bspatom_host_setup", "bspatom_problem_create", "bspatom_problem_destroy",
            "bspatom_problem_sizes", "bspatom_problem_grid", "bspatom_assemble", "bspatom_solve", "bspatom_solve_dev",
            "bspatom_eigvec", "bspatom_eigvecs", "bspatom_dipole_bands", "bspatom_dipole_elements", "bspatom_write_wf", "bspatom_last_timing", "bsp_dsygv_", "bspatom_stage_gemm",
-           "bspatom_stage_standard_form", "bspatom_stage_sy2sb", "bspatom_stage_panel", "bspatom_stage_sb2st", "bspatom_stage_sb2sb", "bspatom_stage_bisect",
+           "bspatom_stage_standard_form", "bspatom_stage_sy2sb", "bspatom_stage_panel", "bspatom_stage_sb2st", "bspatom_stage_sb2sb", "bspatom_stage_bisect", "bspatom_stage_crawford",
            "bspatom_set_option", "bspatom_get_option", "bspatom_kernel_times", "bspatom_kernel_slot_name"]
 
 _lib = None
@@ -73,6 +73,7 @@ def lib():
         L.bspatom_stage_panel.argtypes = [i32, i32, i32, vp, vp, vp]
         L.bspatom_stage_sb2sb.argtypes = [i32, i32, i32, vp]
         L.bspatom_stage_bisect.argtypes = [i32, i32, vp, vp, vp]
+        L.bspatom_stage_crawford.argtypes = [i32, i32, i32, vp, vp, vp, vp]
         L.bsp_dsygv_.restype = None
         L.bspatom_set_option.argtypes = [C.c_char_p, i32]
         L.bspatom_get_option.argtypes = [C.c_char_p, C.POINTER(i32)]
@@ -267,6 +268,17 @@ def stage_sb2sb(AB, n):
     out = np.ascontiguousarray(AB).copy()
     _chk(lib().bspatom_stage_sb2sb(n, npad, batch, _p(out)), "bspatom_stage_sb2sb")
     return out
+
+
+def stage_crawford(SB, HB):
+    """Band route, first stage: upper bands SB (k, n), HB (nl, k, n) -> (AB (nl, npad, 128) with AB[l, j, d] = A_l(j + d, j), info)."""
+    nl, k, n = HB.shape
+    npad = (n + 63) // 64 * 64
+    AB = np.zeros((nl, npad, 128))
+    info = C.c_int32(0)
+    _chk(lib().bspatom_stage_crawford(n, k, nl, _p(np.ascontiguousarray(SB, dtype=np.float64)),
+                                      _p(np.ascontiguousarray(HB, dtype=np.float64)), _p(AB), C.byref(info)), "bspatom_stage_crawford")
+    return AB, info.value
 
 
 def stage_bisect(d, e):

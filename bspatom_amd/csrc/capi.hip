@@ -25,6 +25,8 @@ struct bspatom_problem {
     double *d_SB = nullptr, *d_HB = nullptr, *d_UB = nullptr, *d_rdiag = nullptr;
     double *d_Y = nullptr, *d_C = nullptr, *d_AB = nullptr, *d_d = nullptr, *d_e = nullptr, *d_E = nullptr;
     void *d_work = nullptr, *d_sbctl = nullptr;
+    void *d_cwork = nullptr;         // band route (crawford.hip)
+    int cap_dense = 0, cap_band = 0; // channels the dense buffers (Y, C, work) / the band route's work area are sized for
     int *d_info = nullptr;
     // eigenvector / wave-function scratch
     double *d_vwork = nullptr, *d_vec = nullptr, *d_wfr = nullptr, *d_wfu = nullptr, *d_Esel = nullptr;
@@ -76,6 +78,7 @@ const OptName OPT_TABLE[] = {
     {"poison_c", "BSP_POISON_C", &Options::poison_c}, {"sb2sb_mfma", "BSP_SB2SB_MFMA", &Options::sb2sb_mfma},
     {"ktime", "BSP_KTIME", &Options::ktime}, {"tsqr_regcap", "BSP_TSQR_REGCAP", &Options::tsqr_regcap},
     {"tsqr_max_m", "BSP_TSQR_MAX_M", &Options::tsqr_max_m}, {"sb16_rows", "BSP_SB16_ROWS", &Options::sb16_rows},
+    {"route", "BSP_ROUTE", &Options::route},
 };
 }  // namespace
 
@@ -109,7 +112,8 @@ hipEvent_t kevent()
 const char *const KSLOT_NAMES[KS_COUNT] = {"gemm2_kernel<128,128,MODE 1> (rank-128 update, syr2k)", "gemm2_kernel<64,128,MODE 2> (symm Y = A22 W)",
                                           "panel_qr2_kernel / panel_qr_kernel", "sy2sb chain: G, K (split-K gemm_kernel + splitk_reduce), form_T, tsmm64 (W, Z)",
                                           "sb2sb_mfma_kernel (band 64 -> 16)", "sb16r_kernel / sb16st_kernel (band 16 -> 1)", "bisect3_kernel",
-                                          "band_cholesky_kernel + std_form_kernel"};
+                                          "band_cholesky_kernel + std_form_kernel",
+                                          "crawford_item_kernel and its set-up kernels (band route: pencil -> band 15)"};
 }  // namespace
 void ktime_begin(int slot, hipStream_t st)
 {
@@ -198,9 +202,10 @@ static void free_solve_buffers(bspatom_problem *p)
 {
     hipFree(p->d_SB); hipFree(p->d_HB); hipFree(p->d_UB); hipFree(p->d_rdiag); hipFree(p->d_Y);
     hipFree(p->d_C); hipFree(p->d_AB); hipFree(p->d_d); hipFree(p->d_e); hipFree(p->d_E); hipFree(p->d_work); hipFree(p->d_sbctl);
+    hipFree(p->d_cwork);
     p->d_SB = p->d_HB = p->d_UB = p->d_rdiag = p->d_Y = p->d_C = p->d_AB = p->d_d = p->d_e = p->d_E = nullptr;
-    p->d_work = nullptr; p->d_sbctl = nullptr;
-    p->cap_nl = 0;
+    p->d_work = nullptr; p->d_sbctl = nullptr; p->d_cwork = nullptr;
+    p->cap_nl = 0; p->cap_dense = 0; p->cap_band = 0;
 }
 
 extern "C" void bspatom_problem_destroy(bspatom_problem *p)
@@ -327,16 +332,35 @@ static int ensure_capacity(bspatom_problem *p, int nl)
     BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_HB), b * k * n * sizeof(double)));
     BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_UB), k * n * sizeof(double)));
     BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_rdiag), n * sizeof(double)));
-    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_Y), b * np * np * sizeof(double)));
-    BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_C), b * np * np * sizeof(double)));
     BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_AB), b * ab_stride((int)np) * sizeof(double)));
     BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_d), b * np * sizeof(double)));
     BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_e), b * np * sizeof(double)));
     BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_E), b * n * sizeof(double)));
-    BSP_HIP(hipMalloc(&p->d_work, sy2sb_work_bytes((int)np, 64, nl)));
     BSP_HIP(hipMalloc(&p->d_sbctl, sb2st_ctl_bytes(nl)));
     if (!p->d_info) BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_info), sizeof(int)));
     p->cap_nl = nl;
+    return BSP_OK;
+}
+
+// The buffers of the route the next solve takes, allocated when that route is first used: the dense route's Y and C are
+// 2 x nl x npad^2 doubles (34 GB at C4), the band route's work area 3 x nl x n x 8.
+static int ensure_route_buffers(bspatom_problem *p, int nl, int route)
+{
+    const HostSetup &h = p->hs;
+    const size_t np = p->npad, b = nl;
+    if (route == 2 && nl > p->cap_band) {
+        hipFree(p->d_cwork); p->d_cwork = nullptr; p->cap_band = 0;
+        BSP_HIP(hipMalloc(&p->d_cwork, crawford_work_bytes(h.nfun, h.k, nl)));
+        p->cap_band = nl;
+    }
+    if (route == 1 && nl > p->cap_dense) {
+        hipFree(p->d_Y); hipFree(p->d_C); hipFree(p->d_work);
+        p->d_Y = p->d_C = nullptr; p->d_work = nullptr; p->cap_dense = 0;
+        BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_Y), b * np * np * sizeof(double)));
+        BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_C), b * np * np * sizeof(double)));
+        BSP_HIP(hipMalloc(&p->d_work, sy2sb_work_bytes((int)np, 64, nl)));
+        p->cap_dense = nl;
+    }
     return BSP_OK;
 }
 
@@ -402,10 +426,39 @@ extern "C" int bspatom_assemble(bspatom_problem *p, int l0, int nl, double *SB, 
 }
 
 namespace bsp {
+int pipeline_route(int n, int k)
+{
+    const int r = opts().route;
+    if (r == 1) return 1;
+    if (r == 2) return 2;
+    return (crawford_supported(n, k) && n >= 32) ? 2 : 1;
+}
+
 int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const double *d_HB, const PipeBufs &b,
                      double *d_Eout, hipStream_t st, hipEvent_t *ev, bool with_bisect)
 {
     int rc;
+    const int route = pipeline_route(n, k);
+    if (route == 2) {
+        // band route: the pencil stays banded (crawford.hip), the band-16 chase takes the result as it is
+        if (!crawford_supported(n, k)) {
+            fprintf(stderr, "bspatom: BSP_ROUTE=2 (band route) takes pencils of half-width k - 1 <= 8 and n >= 16 (k = %d, n = %d)\n", k, n);
+            return BSP_ERR_UNSUPPORTED;
+        }
+        if (!b.cwork) return BSP_ERR_ARG;
+        CrawfordWork cw;
+        crawford_carve(b.cwork, n, k, nl, &cw);
+        if (ev) BSP_HIP(hipEventRecord(ev[1], st));
+        if ((rc = crawford_run(n, npad, k, nl, d_SB, d_HB, cw, b.AB, st))) return rc;
+        if (ev) BSP_HIP(hipEventRecord(ev[2], st));
+        if ((rc = launch_sb16st(n, npad, nl, b.AB, b.d, b.e, st, b.status, b.sbctl))) return rc;
+        if (ev) BSP_HIP(hipEventRecord(ev[3], st));
+        if (!with_bisect) return BSP_OK;
+        if ((rc = launch_bisect(n, npad, nl, b.d, b.e, d_Eout, n, st))) return rc;
+        if (ev) BSP_HIP(hipEventRecord(ev[4], st));
+        return BSP_OK;
+    }
+    if (!b.Y || !b.C || !b.work) return BSP_ERR_ARG;
     if (opts().poison_c) BSP_HIP(hipMemsetAsync(b.C, 0xFF, (size_t)nl * npad * npad * sizeof(double), st));
     {
         KScope kt(KS_STDFORM, st);
@@ -454,12 +507,14 @@ static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, dou
     const int n = h.nfun, np = p->npad;
     int rc;
     if ((rc = ensure_capacity(p, nl))) return rc;
+    const int route = pipeline_route(n, h.k);
+    if ((rc = ensure_route_buffers(p, nl, route))) return rc;
     p->last_nl = 0;                                          // valid again only when this solve has completed
     BSP_HIP(hipMemsetAsync(p->d_info, 0, sizeof(int), p->st));
     BSP_HIP(hipEventRecord(p->ev[0], p->st));
     if ((rc = enqueue_assemble(p, l0, nl))) return rc;
     BSP_HIP(hipEventRecord(p->ev[1], p->st));
-    PipeBufs pb{p->d_UB, p->d_rdiag, p->d_Y, p->d_C, p->d_AB, p->d_d, p->d_e, p->d_work, p->d_info, p->d_status, p->d_sbctl};
+    PipeBufs pb{p->d_UB, p->d_rdiag, p->d_Y, p->d_C, p->d_AB, p->d_d, p->d_e, p->d_work, p->d_info, p->d_status, p->d_sbctl, p->d_cwork};
     double *Eout = E_dev_out ? E_dev_out : p->d_E;
     if ((rc = pipeline_enqueue(n, np, h.k, nl, p->d_SB, p->d_HB, pb, Eout, p->st, &p->ev[1], false))) return rc;
     // The consumed eigenvector (l_ini, n0_ini): its eigenvalue alone by multisection as soon as the tridiagonal
@@ -512,6 +567,19 @@ static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, dou
     p->ms[5] = tot;
     if ((rc = check_status(p))) return rc;
     int cinfo = 0;
+    if (route == 2) {
+        // The band route factors the REVERSED overlap.  If that broke down, S is not positive definite: DSYGV's info names the
+        // leading minor of S itself, which the forward factorisation finds.
+        CrawfordWork cw;
+        crawford_carve(p->d_cwork, n, h.k, nl, &cw);
+        BSP_HIP(hipMemcpy(&cinfo, cw.info, sizeof(int), hipMemcpyDeviceToHost));
+        if (cinfo) {
+            if ((rc = launch_band_cholesky(n, h.k, p->d_SB, p->d_UB, p->d_rdiag, p->d_info, p->st))) return rc;
+            BSP_HIP(hipStreamSynchronize(p->st));
+            BSP_HIP(hipMemcpy(&cinfo, p->d_info, sizeof(int), hipMemcpyDeviceToHost));
+            if (!cinfo) cinfo = 1;                           // (cannot happen: both factorisations exist or neither)
+        }
+    } else
     BSP_HIP(hipMemcpy(&cinfo, p->d_info, sizeof(int), hipMemcpyDeviceToHost));
     if (info)
         for (int l = 0; l < nl; ++l) info[l] = cinfo ? n + cinfo : 0;       // DSYGV: n+i, B not PD
@@ -829,6 +897,30 @@ extern "C" int bspatom_stage_sb2sb(int n, int npad, int batch, double *AB)
     if ((rc = launch_sb2sb(n, npad, batch, dAB.p, 0))) return rc;
     BSP_HIP(hipDeviceSynchronize());
     for (int b = 0; b < batch; ++b)
+        BSP_HIP(hipMemcpy(AB + (size_t)b * npad * 128, dAB.p + b * ab_stride(npad), (size_t)npad * 128 * sizeof(double),
+                          hipMemcpyDeviceToHost));
+    return BSP_OK;
+}
+
+extern "C" int bspatom_stage_crawford(int n, int k, int nl, const double *SB, const double *HB, double *AB, int32_t *info)
+{
+    int rc;
+    if ((rc = need_gpu())) return rc;
+    if (n < 1 || k < 2 || nl < 1 || !SB || !HB || !AB) return BSP_ERR_ARG;
+    if (!crawford_supported(n, k)) return BSP_ERR_UNSUPPORTED;
+    const int npad = round_up(n, 64);
+    DevBuf dSB, dHB, dAB, dW;
+    if ((rc = dSB.put(SB, (size_t)k * n)) || (rc = dHB.put(HB, (size_t)nl * k * n)) || (rc = dAB.alloc((size_t)nl * ab_stride(npad))) ||
+        (rc = dW.alloc(crawford_work_bytes(n, k, nl) / sizeof(double) + 1))) return rc;
+    BSP_HIP(hipMemset(dAB.p, 0, (size_t)nl * ab_stride(npad) * sizeof(double)));
+    CrawfordWork cw;
+    crawford_carve(dW.p, n, k, nl, &cw);
+    if ((rc = crawford_run(n, npad, k, nl, dSB.p, dHB.p, cw, dAB.p, 0))) return rc;
+    BSP_HIP(hipDeviceSynchronize());
+    int ci = 0;
+    BSP_HIP(hipMemcpy(&ci, cw.info, sizeof(int), hipMemcpyDeviceToHost));
+    if (info) *info = ci;
+    for (int b = 0; b < nl; ++b)
         BSP_HIP(hipMemcpy(AB + (size_t)b * npad * 128, dAB.p + b * ab_stride(npad), (size_t)npad * 128 * sizeof(double),
                           hipMemcpyDeviceToHost));
     return BSP_OK;

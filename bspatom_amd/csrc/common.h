@@ -59,6 +59,9 @@ struct Options {
                                  // first layout (one tile spread over a wave), kept as the cross-check
     int poison_c = 0;            // test hook: fill the dense C buffer with NaN bit patterns before every solve (nothing outside the
                                  // blocks the standard form writes may ever be read)
+    int route = 0;               // BSP_ROUTE: 0 = by size (the band route wherever crawford_supported), 1 = dense route (standard form, sy2sb,
+                                 // two-step bulge chasing: north_star's letter, and every pencil wider than 8), 2 = band route (crawford.hip:
+                                 // the pencil stays banded; band-16 chase; UNSUPPORTED where it cannot run)
     int ktime = 0;               // 1: HIP events around every launch of the kernels in KSlot (bspatom_kernel_times; bench.py's
                                  // per-kernel roofline entries are measured with it in one extra, untimed step)
 };
@@ -73,7 +76,7 @@ void process_device_latch(int device);
 // Two events per launch, recorded on the launch's own stream; bspatom_kernel_times() sums the elapsed times per slot after
 // the device has drained.  Launches of different streams overlap, so the sums of a slot are sums of launch DURATIONS (what
 // rocprofv3 --kernel-trace --stats reports), not wall time.
-enum KSlot { KS_SYR2K = 0, KS_SYMM, KS_PANEL_QR, KS_CHAIN, KS_SB2SB, KS_SB16ST, KS_BISECT, KS_STDFORM, KS_COUNT };
+enum KSlot { KS_SYR2K = 0, KS_SYMM, KS_PANEL_QR, KS_CHAIN, KS_SB2SB, KS_SB16ST, KS_BISECT, KS_STDFORM, KS_CRAWFORD, KS_COUNT };
 void ktime_begin(int slot, hipStream_t st);
 void ktime_end(int slot, hipStream_t st);
 struct KScope {
@@ -134,6 +137,18 @@ int launch_band_cholesky(int n, int k, const double *d_SB, double *d_UB, double 
 // full = 0: C's lower triangle and first block super-diagonal only (all the reduction reads); 1: the whole matrix
 int launch_standard_form(int n, int npad, int k, int nl, const double *d_HB, const double *d_UB,
                          const double *d_rdiag, double *d_Y, double *d_C, hipStream_t st, int full = 0);
+// crawford.hip: band route -- the banded pencil to a banded standard-form matrix (half-width 15) without the dense C_l
+struct CrawfordWork {
+    double *SBf, *UBf, *rdiagf;  // [k][n] overlap in reversed order, its Cholesky factor, [n] reciprocal pivots
+    double *Qel, *LiB;           // [N][256] elimination transforms, [N][64] inverse diagonal blocks of L (N = ceil(n / 8))
+    double *D, *E, *G;           // [nl][N][64] diagonal / sub-diagonal blocks of the working matrix, the fill in flight
+    int *info;                   // device word: order of the minor at which the Cholesky factorisation of the reversed overlap broke down
+};
+bool crawford_supported(int n, int k);
+size_t crawford_work_bytes(int n, int k, int nl);
+void crawford_carve(void *base, int n, int k, int nl, CrawfordWork *w);
+int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const double *d_HB, const CrawfordWork &w, double *d_AB,
+                 hipStream_t st);
 // sy2sb.hip
 // tsqr.hip: panel factorisation on many workgroups (TSQR + Householder reconstruction), BSP_PANEL_QR=3
 long tsqr_scr_doubles(int npad);
@@ -192,7 +207,10 @@ struct PipeBufs {
     int *info;
     int *status = nullptr;   // device word set to a BSP_ERR_* code by kernels that detect a failure
     void *sbctl = nullptr;   // sb2st pairing/progress control block (sb2st_ctl_bytes(nl))
+    void *cwork = nullptr;   // band route: crawford_work_bytes(n, k, nl); Y, C, work may be null when only that route runs
 };
+// 1 = dense route, 2 = band route, for a pencil of this size under the current switches (BSP_ROUTE)
+int pipeline_route(int n, int k);
 size_t pipe_bytes_per_channel(int npad);
 int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const double *d_HB,
                      const PipeBufs &b, double *d_Eout, hipStream_t st, hipEvent_t *ev, bool with_bisect = true);

@@ -1,0 +1,392 @@
+// crawford.hip -- band route: the banded pencil (H_l, S) to a BANDED standard-form matrix, without the dense C_l.
+//
+// Replaces DPOTRF + DSYGST + the dense part of DSYTRD inside DSYGV (reference call matrices.f90:248) for pencils whose
+// half-width k - 1 is at most 8 (every BASELINE config except C5): the dense route forms C_l = L^-1 H_l L^-T (n^2 doubles) and
+// reduces it to band form in 4/3 n^3 flop; here the band survives the reduction (Crawford 1973; blocked as in Lang 2019):
+//
+//   L = R_0 R_1 ... R_{N-1}, R_j = identity except block row j = [L_{j,j-1}, L_jj]  (8 x 8 blocks, N = ceil(n / 8)).
+//   Step j ("elimination"): A <- R_j^-1 A R_j^-T touches block row / column j only and leaves ONE 8 x 8 block of fill, at
+//   (j, j-2).  It is chased off the top: item (j, s), p = j - 2 - s, takes the RQ factorisation [A(p+2,p), A(p+2,p+1)] = [0 R] Q^T
+//   and applies Q to block columns and rows (p, p+1), which moves the fill to (p+1, p-1).  Q mixes blocks below j only and
+//   therefore commutes with every later R_k.  The result is block tridiagonal with full 8 x 8 blocks: half-width 15, the input
+//   of the band-16 chase (sbr2.hip); 6 n^2 b flop instead of 4/3 n^3.
+//
+// Both kinds of work are ONE shape: a 16 x 16 matrix Q applied as a congruence to the window W = [D_p E_p^T; E_p D_{p+1}] and
+// from the left to the block in front of it, [E_{p-1}; 0] -> [E_{p-1}'; fill].  For a chase item Q is orthogonal (eight
+// Householder reflectors from the RQ loop), for the elimination it is R_j^-T restricted to the window, [I -K^T; 0 Li^T] with
+// Li = L_jj^-1, K = Li L_{j,j-1} -- formed once per solve, S being the same for every channel.
+//
+// Schedule: item (j, s) in wavefront t = 2 j + s, the elimination of step j in wavefront 2 j - 1; the items of one wavefront
+// touch disjoint blocks (tools/proto_crawford.py checks it with a write log), so a wavefront is one launch over all channels:
+// no flags, no spinning, bit-identical by construction.  3 N - 5 launches.
+//
+// One WAVE per item, no LDS memory.  16 x 16 matrices live in the accumulator layout of v_mfma_f64_16x16x4 (register q of lane
+// l holds M[4 q + (l >> 4)][l & 15]): a matrix row is a DPP row of 16 lanes, so the RQ loop's dot products are row rotations
+// (row_ror 8, 4, 2, 1: every lane ends with the same bits), and the layout is at once the B operand of the matrix cores and --
+// for the transpose -- the A operand: P = W Q and W' = Q^T P need no transposition because W is symmetric.
+//
+// ORIENTATION.  The reduction runs on the index-REVERSED pencil: the fill is chased towards large r, where the entries of H are
+// small.  Chased towards r = 0 it passes through the centrifugal term l (l + 1) / r^2 of every row above it and the eigenvalues
+// next to zero lose a factor of 50 at l = 14 (0.015 against 0.0003 eps lambda_max, measured against 113-bit truth by the
+// prototype).  The band handed to the tridiagonalisation is stored in the original order again.
+#include "common.h"
+
+namespace bsp {
+namespace {
+
+constexpr int CB = 8;              // block size = largest half-width of the pencil this route takes
+constexpr int CBB = CB * CB;
+
+template <int CTRL>
+__device__ __forceinline__ double cw_dpp(double x)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, 0xf, 0xf, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, 0xf, 0xf, true);
+    return r.d;
+}
+// sum over the 16 lanes of a DPP row, the same bits in every lane (a butterfly of commutative additions)
+__device__ __forceinline__ double cw_rowsum(double x)
+{
+    x += cw_dpp<0x128>(x);         // row_ror:8
+    x += cw_dpp<0x124>(x);
+    x += cw_dpp<0x122>(x);
+    x += cw_dpp<0x121>(x);
+    return x;
+}
+__device__ __forceinline__ double cw_bperm(double x, int srclane)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_ds_bpermute(srclane << 2, u.i[0]);
+    r.i[1] = __builtin_amdgcn_ds_bpermute(srclane << 2, u.i[1]);
+    return r.d;
+}
+template <int L>
+__device__ __forceinline__ double cw_lane(double x)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_readlane(u.i[0], L);
+    r.i[1] = __builtin_amdgcn_readlane(u.i[1], L);
+    return r.d;
+}
+
+// One step of the RQ factorisation of X = [F E] (8 x 16; x0: rows 0-3, x1: rows 4-7; lane (g, c) holds rows g and 4 + g at
+// column c): the reflector H = I - tau v v^T on columns 0 .. 8 + I that leaves row I as (0 .. 0, beta, *), applied to the rows
+// above it and accumulated into Q <- Q H.  Rows below I have zeros wherever v has not and are left as they are.
+template <int I>
+__device__ __forceinline__ void rq_step(double &x0, double &x1, double (&q)[4], const int g, const int c)
+{
+    constexpr int LEN = CB + I, GI = I & 3;
+    double &xr = (I < 4) ? x0 : x1;
+    const double xi = cw_bperm(xr, GI * 16 + c);                       // row I in every DPP row
+    const double sig = cw_rowsum(c < LEN ? xi * xi : 0.0);
+    const double alpha = cw_lane<LEN>(xi);
+    const double a2s = alpha * alpha + sig;
+    const bool ok = (a2s > 1e-280) && (sig != 0.0);                    // nothing (numerically) left of the pivot: H = I
+    const double nrm = sqrt(ok ? a2s : 1.0);
+    const double bt = (alpha >= 0.0) ? -nrm : nrm;
+    const double tau = ok ? (bt - alpha) / bt : 0.0;
+    const double scale = ok ? 1.0 / (alpha - bt) : 0.0;
+    const double beta = ok ? bt : alpha;
+    const double v = (c < LEN) ? xi * scale : ((c == LEN) ? 1.0 : 0.0);
+    if (I > 0) {
+        const double w0 = cw_rowsum(x0 * v);
+        x0 = fma(-tau * w0, v, x0);
+    }
+    if (I > 4) {
+        const double w1 = cw_rowsum(x1 * v);
+        x1 = fma(-tau * w1, v, x1);
+    }
+    if (g == GI) xr = (c < LEN) ? 0.0 : ((c == LEN) ? beta : xr);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double wq = cw_rowsum(q[r] * v);
+        q[r] = fma(-tau * wq, v, q[r]);
+    }
+}
+
+__device__ __forceinline__ double4_t cw_mfma(double a, double b, double4_t acc)
+{
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+}
+
+// Wavefront t: chase items j = jlo .. jlo + nch - 1 (s = t - 2 j, p = j - 2 - s) and, if jel > 0, the elimination of step jel
+// (window (jel - 1, jel)).  grid = (ceil(items / 4), channels), one wave per item.
+__global__ __launch_bounds__(256) void crawford_item_kernel(int N, int t, int jlo, int nch, int jel,
+                                                           const double *__restrict__ Qel, double *Dall, double *Eall, double *Gall)
+{
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15, c8 = c & 7;
+    const bool left = c < CB;
+    bool elim;
+    int j, p;
+    if (idx < nch) { elim = false; j = jlo + idx; p = j - 2 - (t - 2 * j); }
+    else if (idx == nch && jel > 0) { elim = true; j = jel; p = j - 1; }
+    else return;
+    const size_t chn = (size_t)blockIdx.y * N * CBB;
+    double *D = Dall + chn, *E = Eall + chn, *G = Gall + chn;
+    double *D0 = D + (size_t)p * CBB, *D1 = D0 + CBB, *E0 = E + (size_t)p * CBB;
+
+    // ---- loads: the window, symmetric by construction (lower triangles of D), and the block in front of it ----
+    double w[4], sd[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int R = 4 * r + g;
+        const int hi = R > c8 ? R : c8, lo = R > c8 ? c8 : R;
+        w[r] = *(left ? D0 + hi * CB + lo : E0 + c8 * CB + R);
+        w[r + 2] = *(left ? E0 + R * CB + c8 : D1 + hi * CB + lo);
+    }
+    const bool side = p >= 1;
+    {
+        const double *Em = E + (size_t)(side ? p - 1 : 0) * CBB;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const double v = Em[(4 * r + g) * CB + c8];
+            sd[r] = (side && left) ? v : 0.0;
+        }
+    }
+    double q[4], x0 = 0.0, x1 = 0.0, xt[2] = {0.0, 0.0};
+    const bool has_x = elim && (j + 1 <= N - 1);
+    if (!elim) {
+        const double *src = left ? G + (size_t)p * CBB + c8 : E + (size_t)(p + 1) * CBB + c8;
+        x0 = src[g * CB];
+        x1 = src[(4 + g) * CB];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q[r] = (4 * r + g == c) ? 1.0 : 0.0;
+        rq_step<7>(x0, x1, q, g, c);
+        rq_step<6>(x0, x1, q, g, c);
+        rq_step<5>(x0, x1, q, g, c);
+        rq_step<4>(x0, x1, q, g, c);
+        rq_step<3>(x0, x1, q, g, c);
+        rq_step<2>(x0, x1, q, g, c);
+        rq_step<1>(x0, x1, q, g, c);
+        rq_step<0>(x0, x1, q, g, c);
+    } else {
+        const double *Qj = Qel + (size_t)j * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q[r] = Qj[(4 * r + g) * 16 + c];
+        const double *Ej = E + (size_t)(has_x ? j : 0) * CBB;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const double v = Ej[c8 * CB + 4 * r + g];                 // (X^T)[8 + 4 r + g][c] = E_j[c][4 r + g]
+            xt[r] = (has_x && left) ? v : 0.0;
+        }
+    }
+
+    // ---- W' = Q^T (W Q) ----
+    double4_t P = {0.0, 0.0, 0.0, 0.0}, Wn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) P = cw_mfma(w[r], q[r], P);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Wn = cw_mfma(q[r], P[r], Wn);
+    // ---- [E_{p-1}'; fill] = Q^T [E_{p-1}; 0] ----
+    double4_t O = {0.0, 0.0, 0.0, 0.0};
+    O = cw_mfma(q[0], sd[0], O);
+    O = cw_mfma(q[1], sd[1], O);
+
+    // ---- stores ----
+    if (left) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            D0[(4 * r + g) * CB + c8] = Wn[r];
+            E0[(4 * r + g) * CB + c8] = Wn[r + 2];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) D1[(4 * r + g) * CB + c8] = Wn[r + 2];
+    }
+    if (side && left) {
+        double *Em = E + (size_t)(p - 1) * CBB, *Gm = G + (size_t)(p - 1) * CBB;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (!elim) Em[(4 * r + g) * CB + c8] = O[r];              // the elimination leaves E_{p-1} as it is (Q^T = [I 0; -K Li])
+            Gm[(4 * r + g) * CB + c8] = O[r + 2];
+        }
+    }
+    if (!elim) {
+        if (!left) {
+            double *E1 = E + (size_t)(p + 1) * CBB;
+            E1[g * CB + c8] = x0;
+            E1[(4 + g) * CB + c8] = x1;
+        }
+    } else if (has_x) {
+        // E_j <- E_j Li^T, as (X Q)^T = Q^T X^T with X = [0 E_j]: rows 8 .. 15 of the product hold (E_j Li^T)^T
+        double4_t T = {0.0, 0.0, 0.0, 0.0};
+        T = cw_mfma(q[2], xt[0], T);
+        T = cw_mfma(q[3], xt[1], T);
+        if (left) {
+            double *Ej = E + (size_t)j * CBB;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) Ej[c8 * CB + 4 * r + g] = T[r + 2];
+        }
+    }
+}
+
+// index-reversed overlap band: SBf[d][i] = S_f(i, i + d) = S(n-1-i-d, n-1-i)
+__global__ void crawford_flip_kernel(int n, int k, const double *__restrict__ SB, double *__restrict__ SBf)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * k) return;
+    const int d = idx / n, i = idx % n;
+    SBf[idx] = (i + d < n) ? SB[(size_t)d * n + (n - 1 - i - d)] : 0.0;
+}
+
+// Per block j: Li = L_jj^-1, K = Li L_{j,j-1} (L = U^T from the Cholesky factor of the reversed overlap, identity beyond n),
+// LiB[j] = Li (row-major 8 x 8) and Qel[j] = [I -K^T; 0 Li^T] (row-major 16 x 16).  One wave per block.
+__global__ __launch_bounds__(64) void crawford_setup_kernel(int n, int k, const double *__restrict__ UBf, double *__restrict__ LiB,
+                                                           double *__restrict__ Qel)
+{
+    __shared__ double Ld[CB][CB + 1], M[CB][CB + 1], Li[CB][CB + 1];
+    const int j = blockIdx.x, t = threadIdx.x, r = t >> 3, c = t & 7, b = k - 1;
+    const int i = CB * j + r;
+    {
+        const int ic = CB * j + c, d = r - c;
+        double v = 0.0;
+        if (i >= n) v = (r == c) ? 1.0 : 0.0;
+        else if (d >= 0 && d <= b) v = UBf[(size_t)d * n + ic];           // L(i, ic) = U(ic, i)
+        Ld[r][c] = v;
+        const int im = CB * (j - 1) + c, dm = CB + r - c;
+        double m = 0.0;
+        if (j > 0 && i < n && dm <= b) m = UBf[(size_t)dm * n + im];
+        M[r][c] = m;
+        Li[r][c] = 0.0;
+    }
+    __syncthreads();
+    if (t < CB) {                                                          // column t of Li by forward substitution
+        double x[CB];
+#pragma unroll
+        for (int rr = 0; rr < CB; ++rr) {
+            double s = (rr == t) ? 1.0 : 0.0;
+#pragma unroll
+            for (int kk = 0; kk < CB; ++kk)
+                if (kk < rr && kk >= t) s -= Ld[rr][kk] * x[kk];
+            x[rr] = (rr >= t) ? s / Ld[rr][rr] : 0.0;
+        }
+#pragma unroll
+        for (int rr = 0; rr < CB; ++rr) Li[rr][t] = x[rr];
+    }
+    __syncthreads();
+    double kv = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < CB; ++kk) kv += Li[r][kk] * M[kk][c];            // K[r][c]
+    LiB[(size_t)j * CBB + t] = Li[r][c];
+    double *Q = Qel + (size_t)j * 256;
+    Q[r * 16 + c] = (r == c) ? 1.0 : 0.0;                                  // I
+    Q[c * 16 + CB + r] = -kv;                                              // -K^T: Q[c][8 + r] = -K[r][c]
+    Q[(CB + r) * 16 + c] = 0.0;
+    Q[(CB + c) * 16 + CB + r] = Li[r][c];                                  // Li^T
+}
+
+// D_p, E_p of the index-reversed H_l (upper band HB[d][i] = H(i, i + d)); block 0 is taken through step 0 of the
+// elimination here: D_0 <- Li_0 D_0 Li_0^T, E_0 <- E_0 Li_0^T.  grid = (N, channels), one wave per block pair.
+__global__ __launch_bounds__(64) void crawford_init_kernel(int n, int k, int N, const double *__restrict__ HBall,
+                                                          const double *__restrict__ LiB, double *Dall, double *Eall)
+{
+    __shared__ double Ds[CB][CB + 1], Es[CB][CB + 1], Ls[CB][CB + 1], Ts[CB][CB + 1];
+    const int p = blockIdx.x, t = threadIdx.x, r = t >> 3, c = t & 7, b = k - 1;
+    const double *HB = HBall + (size_t)blockIdx.y * k * n;
+    auto Hf = [&](int i, int i2) -> double {                               // reversed indices
+        const int hi = i > i2 ? i : i2, d = hi - (i > i2 ? i2 : i);
+        return (hi < n && d <= b) ? HB[(size_t)d * n + (n - 1 - hi)] : 0.0;
+    };
+    double dv = Hf(CB * p + r, CB * p + c), ev = Hf(CB * (p + 1) + r, CB * p + c);
+    if (p == 0) {
+        Ds[r][c] = dv; Es[r][c] = ev; Ls[r][c] = LiB[t];
+        __syncthreads();
+        double s = 0.0, e2 = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < CB; ++kk) { s += Ls[r][kk] * Ds[kk][c]; e2 += Es[r][kk] * Ls[c][kk]; }
+        Ts[r][c] = s;
+        __syncthreads();
+        s = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < CB; ++kk) s += Ts[r][kk] * Ls[c][kk];
+        dv = s; ev = e2;
+    }
+    const size_t o = ((size_t)blockIdx.y * N + p) * CBB + t;
+    Dall[o] = dv;
+    Eall[o] = ev;
+}
+
+// block tridiagonal (reversed order) -> lower band storage of the band-16 chase in the ORIGINAL order:
+// AB[j * 128 + d] = A(j + d, j), d = 0 .. 31 (zero beyond the half-width 15 and beyond the matrix)
+__global__ void crawford_band_kernel(int n, int npad, int N, const double *__restrict__ Dall, const double *__restrict__ Eall,
+                                     double *__restrict__ ABall)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npad * 32) return;
+    const int j = idx >> 5, d = idx & 31;
+    const size_t ch = blockIdx.y;
+    double v = 0.0;
+    if (j + d < n && d < 2 * CB) {
+        const int ihi = n - 1 - j, ilo = ihi - d;                          // reversed indices, ihi >= ilo
+        const int P = ihi >> 3, Pc = ilo >> 3;                             // P - Pc = 2 (d >= 9 only): outside the block tridiagonal
+        const double *blk = (P == Pc ? Dall : Eall) + (ch * N + Pc) * CBB;
+        v = (P - Pc <= 1) ? blk[(ihi & 7) * CB + (ilo & 7)] : 0.0;
+    }
+    ABall[ch * ab_stride(npad) + (size_t)j * 128 + d] = v;
+}
+
+}  // namespace
+
+size_t crawford_work_bytes(int n, int k, int nl)
+{
+    const size_t N = (n + CB - 1) / CB;
+    return ((size_t)2 * k * n + n + N * 256 + N * CBB + (size_t)3 * nl * N * CBB) * sizeof(double) + 64;
+}
+
+void crawford_carve(void *base, int n, int k, int nl, CrawfordWork *w)
+{
+    const size_t N = (n + CB - 1) / CB;
+    double *p = static_cast<double *>(base);
+    w->SBf = p; p += (size_t)k * n;
+    w->UBf = p; p += (size_t)k * n;
+    w->rdiagf = p; p += n;
+    w->Qel = p; p += N * 256;
+    w->LiB = p; p += N * CBB;
+    w->D = p; p += (size_t)nl * N * CBB;
+    w->E = p; p += (size_t)nl * N * CBB;
+    w->G = p; p += (size_t)nl * N * CBB;
+    w->info = reinterpret_cast<int *>(p);
+}
+
+bool crawford_supported(int n, int k) { return k >= 2 && k - 1 <= CB && n >= 2 * CB; }
+
+// d_SB, d_HB: upper bands of S and of nl channels of H; d_AB: the band storage of the band-16 chase (ab_stride per channel).
+// w.info (device) receives the order of the minor of the REVERSED overlap at which its Cholesky factorisation broke down, or 0.
+int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const double *d_HB, const CrawfordWork &w, double *d_AB,
+                 hipStream_t st)
+{
+    if (!crawford_supported(n, k)) return BSP_ERR_UNSUPPORTED;
+    const int N = (n + CB - 1) / CB;
+    int rc;
+    KScope kt(KS_CRAWFORD, st);
+    BSP_HIP(hipMemsetAsync(w.info, 0, sizeof(int), st));
+    hipLaunchKernelGGL(crawford_flip_kernel, dim3((n * k + 255) / 256), dim3(256), 0, st, n, k, d_SB, w.SBf);
+    if ((rc = launch_band_cholesky(n, k, w.SBf, w.UBf, w.rdiagf, w.info, st))) return rc;
+    hipLaunchKernelGGL(crawford_setup_kernel, dim3(N), dim3(64), 0, st, n, k, w.UBf, w.LiB, w.Qel);
+    hipLaunchKernelGGL(crawford_init_kernel, dim3(N, nl), dim3(64), 0, st, n, k, N, d_HB, w.LiB, w.D, w.E);
+    BSP_HIP(hipGetLastError());
+    // wavefront t: eliminations 2 j - 1 = t (1 <= j <= N - 1), chase items 2 j + s = t with 0 <= s <= j - 2, j <= N - 1
+    const int tmax = (N >= 3) ? 3 * N - 5 : (N == 2 ? 1 : 0);
+    for (int t = 1; t <= tmax; ++t) {
+        const int jel = ((t & 1) && (t + 1) / 2 <= N - 1) ? (t + 1) / 2 : 0;
+        const int jlo = (t + 2 + 2) / 3;                                  // ceil((t + 2) / 3)
+        const int jhi = (t / 2 < N - 1) ? t / 2 : N - 1;
+        const int nch = (jhi >= jlo && jlo >= 2) ? jhi - jlo + 1 : 0;
+        const int items = nch + (jel ? 1 : 0);
+        if (items == 0) continue;
+        hipLaunchKernelGGL(crawford_item_kernel, dim3((items + 3) / 4, nl), dim3(256), 0, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E,
+                           w.G);
+    }
+    BSP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(crawford_band_kernel, dim3((npad * 32 + 255) / 256, nl), dim3(256), 0, st, n, npad, N, w.D, w.E, d_AB);
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
+
+}  // namespace bsp

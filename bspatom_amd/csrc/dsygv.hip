@@ -223,15 +223,16 @@ extern "C" void bsp_dsygv_(const int *itype, const char *jobz, const char *uplo,
             HB[(size_t)d * n + i] = at(a, lda, i, i + d);
         }
     DBuf<double> dSB, dHB, dUB, dr, dY, dC, dAB, dd, de, dE, dvw, dvec;
-    DBuf<char> dwork, dctl;
+    DBuf<char> dwork, dctl, dcw;
     DBuf<int> dinfo, dchan, dstatus;
     const size_t nn = (size_t)npad * npad;
+    const int route = pipeline_route(n, k);              // 2: the band route (half-width <= 8): no dense matrix at all
     bool ok = dSB.alloc((size_t)k * n) == hipSuccess && dHB.alloc((size_t)k * n) == hipSuccess &&
-              dUB.alloc((size_t)k * n) == hipSuccess && dr.alloc(n) == hipSuccess && dY.alloc(nn) == hipSuccess &&
-              dC.alloc(nn) == hipSuccess && dAB.alloc(ab_stride(npad)) == hipSuccess &&
+              dUB.alloc((size_t)k * n) == hipSuccess && dr.alloc(n) == hipSuccess && dAB.alloc(ab_stride(npad)) == hipSuccess &&
               dd.alloc(npad) == hipSuccess && de.alloc(npad) == hipSuccess && dE.alloc(n) == hipSuccess &&
-              dwork.alloc(sy2sb_work_bytes(npad, 64, 1)) == hipSuccess && dinfo.alloc(1) == hipSuccess &&
-              dstatus.alloc(1) == hipSuccess && dctl.alloc(sb2st_ctl_bytes(1)) == hipSuccess;
+              dinfo.alloc(1) == hipSuccess && dstatus.alloc(1) == hipSuccess && dctl.alloc(sb2st_ctl_bytes(1)) == hipSuccess;
+    if (ok && route == 2) ok = dcw.alloc(crawford_work_bytes(n, k, 1)) == hipSuccess;
+    else if (ok) ok = dY.alloc(nn) == hipSuccess && dC.alloc(nn) == hipSuccess && dwork.alloc(sy2sb_work_bytes(npad, 64, 1)) == hipSuccess;
     auto fail = [&](const char *what) {
         fprintf(stderr, "bsp_dsygv_: %s\n", what);
         *info = n;
@@ -243,8 +244,11 @@ extern "C" void bsp_dsygv_(const int *itype, const char *jobz, const char *uplo,
     hipMemset(dstatus.p, 0, sizeof(int));
     // a status word and a control block of its own: a ring time-out or an exchange-frame violation of the bulge
     // chasing must not end in info = 0 (round-1 advisor finding)
-    PipeBufs pb{dUB.p, dr.p, dY.p, dC.p, dAB.p, dd.p, de.p, dwork.p, dinfo.p, dstatus.p, dctl.p};
-    int rc = pipeline_enqueue(n, npad, k, 1, dSB.p, dHB.p, pb, dE.p, 0, nullptr);
+    PipeBufs pb{dUB.p, dr.p, dY.p, dC.p, dAB.p, dd.p, de.p, dwork.p, dinfo.p, dstatus.p, dctl.p, dcw.p};
+    int rc = BSP_OK;
+    // the band route factors the reversed overlap; DSYGV returns the factor of B itself and names ITS leading minor in info
+    if (route == 2) rc = launch_band_cholesky(n, k, dSB.p, dUB.p, dr.p, dinfo.p, 0);
+    if (!rc) rc = pipeline_enqueue(n, npad, k, 1, dSB.p, dHB.p, pb, dE.p, 0, nullptr);
     if (rc || hipDeviceSynchronize() != hipSuccess) { fail("the solve pipeline failed"); return; }
     int cinfo = 0, cstat = 0;
     hipMemcpy(&cinfo, dinfo.p, sizeof(int), hipMemcpyDeviceToHost);

@@ -127,7 +127,8 @@ int bspatom_last_timing(const bspatom_problem *p, double ms[6]);
  * of the kernels below is bracketed by two HIP events on its own stream; this call waits for the device, sums the elapsed
  * times and launch counts per slot since the previous call into ms[] / launches[] (cap >= the slot count, which it returns)
  * and forgets them.  Slots: 0 rank-128 update (syr2k), 1 symm, 2 panel QR, 3 the small products of the panel chain,
- * 4 sb2sb_mfma_kernel, 5 sb16r_kernel (sb16st_kernel with BSP_SB16_ROWS=0), 6 batched bisection, 7 Cholesky + standard form; bspatom_kernel_slot_name(i)
+ * 4 sb2sb_mfma_kernel, 5 sb16r_kernel (sb16st_kernel with BSP_SB16_ROWS=0), 6 batched bisection, 7 Cholesky + standard form,
+ * 8 the band route's reduction (crawford.hip); bspatom_kernel_slot_name(i)
  * names them.  Launches on different streams overlap: the sums are sums of launch durations, not wall time. */
 int bspatom_kernel_times(double *ms, int32_t *launches, int cap);
 const char *bspatom_kernel_slot_name(int slot);
@@ -170,6 +171,12 @@ int bspatom_stage_panel(int npad, int c0, int batch, double *A, double *V, doubl
 int bspatom_stage_sb2st(int n, int npad, int batch, const double *AB, double *d, double *e);
 /* first half of the two-step route (sb2st_version 9): band 64 -> band 16 in place, same layout */
 int bspatom_stage_sb2sb(int n, int npad, int batch, double *AB);
+/* band route (csrc/crawford.hip; BSP_ROUTE): the banded pencil (H_l, S) of nl channels, upper bands as bspatom_assemble returns
+ * them, to the banded standard-form matrix orthogonally similar to L^-1 H_l L^-T (S = L L^T), half-width 2 (k - 1) - 1 <= 15,
+ * in the layout above: AB[l][d + j*128] = A_l(j + d, j), npad = n rounded up to 64.  k - 1 <= 8.  info: 0, or the order of the
+ * minor at which the factorisation of the (index-reversed) overlap broke down.  Replaces DPOTRF + DSYGST + the dense stage of
+ * DSYTRD inside DSYGV (matrices.f90:248) in 6 n^2 (k - 1) flop and no dense matrix. */
+int bspatom_stage_crawford(int n, int k, int nl, const double *SB, const double *HB, double *AB, int32_t *info);
 /* eigenvalues of tridiagonal matrices, ascending */
 int bspatom_stage_bisect(int n, int batch, const double *d, const double *e, double *w);
 

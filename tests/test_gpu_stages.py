@@ -427,3 +427,56 @@ def test_assemble_high_l_bit_exact_vs_oracle(l0):
          % (l0, lam / w[0], np.max(np.abs(E[0] - w) / np.abs(w)), eg.max(), er.max()))
     assert np.all(eg <= np.maximum(1e-10, 2.0 * er.max()))
     prob.close()
+
+
+# ------------------------------------------------------------------------------------------------
+def _random_pencil(n, k, nl, seed):
+    """upper bands of a random banded pencil: S diagonally dominant (positive definite), H symmetric and graded"""
+    rng = np.random.default_rng(seed)
+    SB = np.zeros((k, n)); HB = np.zeros((nl, k, n))
+    SB[0] = 2.0 * k + rng.random(n)
+    grade = np.exp(-4.0 * np.arange(n) / n)                     # large entries first, like the centrifugal term
+    for d in range(1, k):
+        SB[d, :n - d] = rng.standard_normal(n - d)
+    for l in range(nl):
+        for d in range(k):
+            HB[l, d, :n - d] = rng.standard_normal(n - d) * np.sqrt(grade[:n - d] * grade[d:]) * (1 + l)
+    return SB, HB
+
+
+def _dense_upper(B):
+    k, n = B.shape
+    M = np.zeros((n, n))
+    for d in range(k):
+        i = np.arange(n - d)
+        M[i, i + d] = B[d, :n - d]; M[i + d, i] = B[d, :n - d]
+    return M
+
+
+@pytest.mark.parametrize("n,k,nl", [(16, 9, 1), (40, 9, 2), (100, 9, 2), (127, 7, 1), (250, 5, 2), (1000, 9, 2), (333, 2, 1),
+                                    (2048, 9, 1)])
+def test_crawford_band(n, k, nl):
+    """Band route, first stage (csrc/crawford.hip): the banded pencil to a banded standard-form matrix of half-width <= 15.
+    Its eigenvalues are the pencil's (scipy's generalized banded solver on the same bands); nothing is stored beyond the
+    half-width; the result does not change from run to run or with the number of channels in the batch."""
+    import scipy.linalg as sla
+    SB, HB = _random_pencil(n, k, nl, 11 * n + k)
+    AB, info = capi.stage_crawford(SB, HB)
+    AB2, _ = capi.stage_crawford(SB, HB)
+    AB1, _ = capi.stage_crawford(SB, HB[:1])
+    assert info == 0
+    assert np.array_equal(AB, AB2) and np.array_equal(AB[0], AB1[0])
+    assert np.all(AB[:, :, 16:] == 0.0)
+    for l in range(nl):
+        ref = sla.eigh(_dense_upper(HB[l]), _dense_upper(SB), eigvals_only=True)
+        ev = _band_eigs(AB[l], n, 15)
+        err = np.max(np.abs(ev - ref)) / np.max(np.abs(ref))
+        note("crawford n %d k %d l %d: eigenvalues of the band vs scipy eigh(H, S): %.2e of |lambda|_max" % (n, k, l, err))
+        assert err < 2e-14 * np.sqrt(n)                          # both sides carry ~eps cond(S) |lambda|_max
+
+
+def test_crawford_not_positive_definite():
+    SB, HB = _random_pencil(64, 9, 1, 5)
+    SB[0, 20] = -1.0
+    _, info = capi.stage_crawford(SB, HB)
+    assert info != 0

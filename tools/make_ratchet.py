@@ -1,11 +1,22 @@
 #!/usr/bin/env python3
-"""make_ratchet.py -- measure the GPU-vs-truth figures of every case that has a 113-bit truth fixture and write
-tests/golden/accuracy_ratchet.json (tests/tests_truth.py::ratchet_check holds the -m gpu tests to 2 x these).  Run on the
-GPU box; the file lands in gpurun_out/ and is copied next to the truth fixtures by hand:
+"""make_ratchet.py -- measure the GPU-vs-truth figures of every case that has a 113-bit truth fixture and UPDATE
+tests/golden/accuracy_ratchet.json (tests/tests_truth.py::ratchet_check holds the -m gpu tests to 2 x its `best` figures).
 
-    python tools/make_ratchet.py [case ...] > gpurun_out/ratchet.log     # -> gpurun_out/accuracy_ratchet.json
+The file only ever tightens: per case and gated figure `best` = min(committed best, this measurement); `last` records this
+measurement and the hash of the kernel sources it was taken with.  A measurement OVER the committed gate is reported, leaves
+`best` as it is and makes the script exit 1 -- unless the figure is named with
+
+    --allow-regress case:figure:"the eigenvalue, its absolute error, the reference's, why the route is kept"
+
+which writes an `override` entry (bar = 2 x this measurement, the reason verbatim) into the JSON for a reviewer to see.
+Run on the GPU box; the result lands in gpurun_out/accuracy_ratchet.json and is copied over the committed file BY HAND after
+reading the diff:
+
+    python tools/make_ratchet.py [--route N] [--allow-regress ...] [case ...] > gpurun_out/ratchet.log
 """
+import argparse
 import glob
+import hashlib
 import json
 import os
 import sys
@@ -14,27 +25,70 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from bspatom_amd import capi                      # noqa: E402
-from bspatom_amd.namelist import read_namelists  # noqa: E402
-from tests_truth import truth_stats, aggregate_stats   # noqa: E402
+from tests_truth import truth_stats, aggregate_stats, ratchet_violations, GATED, RATCHET_FILE   # noqa: E402
 
 G = os.path.join(ROOT, "tests", "golden")
 
 
-def inp_of(name):
-    nl = read_namelists(open(os.path.join(G, "inputs", name + ".inp")).read())
-    kw = {}
-    kw.update(nl["vars_bsp"]); kw.update(nl["vars_tise"])
-    return capi.make_input(**kw)
+def csrc_sha():
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "bspatom_amd", "csrc", "*.hip")) + [os.path.join(ROOT, "bspatom_amd", "csrc", "common.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def merge(entry, a, sha, allow, name, route):
+    """fold the measurement `a` into the committed entry; returns the violated gates that were not allowed"""
+    linear = entry.get("kind_grid", 0) == 0
+    bad = [] if not entry.get("best") else ratchet_violations(entry, a, linear)
+    best = dict(entry.get("best") or {})
+    for fig in GATED:
+        old = best.get(fig)
+        best[fig] = a[fig] if old is None else min(old, a[fig])
+    entry["best"] = best
+    entry["last"] = {k: a[k] for k in ("worst_rel", "max_abs", "near_zero", "n_beyond")}
+    entry["last"]["csrc_sha16"] = sha
+    entry["last"]["route"] = route
+    left = []
+    for fig, val, bar in bad:
+        why = allow.get((name, fig))
+        if why:
+            entry.setdefault("override", {})[fig] = {"bar": (max(int(2 * val), val + 2) if fig == "n_beyond" else 2.0 * val),
+                                                     "measured": val, "gate_without_override": bar, "why": why, "csrc_sha16": sha}
+        else:
+            left.append((fig, val, bar))
+    return left
 
 
 def main():
-    cases = sys.argv[1:] or sorted(os.path.basename(f)[6:-4] for f in glob.glob(os.path.join(G, "truth_*.npz")))
-    out = {"source": "tools/make_ratchet.py on MI355X: default route of libbspatom, all channels of the case in one batch",
-           "figures": "worst_rel = max |E_gpu - truth| / |truth| over the stored truth set; n_beyond = eigenvalues of the set beyond "
-                      "1e-10 relative; near_zero = max |E_gpu - truth| over the 24 truth eigenvalues nearest zero of a channel, in "
-                      "units of eps * lambda_max, maximum over channels", "cases": {}}
-    old = os.path.join(ROOT, "gpurun_out", "accuracy_ratchet.json")
+    ap = argparse.ArgumentParser()
+    ap.add_argument("cases", nargs="*")
+    ap.add_argument("--route", type=int, default=None, help="bspatom_set_option('route', N) for the measurement (default: the library's default route)")
+    ap.add_argument("--allow-regress", action="append", default=[], metavar="case:figure:reason")
+    args = ap.parse_args()
+    from bspatom_amd import capi
+    from bspatom_amd.namelist import read_namelists
+
+    def inp_of(name):
+        nl = read_namelists(open(os.path.join(G, "inputs", name + ".inp")).read())
+        kw = {}
+        kw.update(nl["vars_bsp"]); kw.update(nl["vars_tise"])
+        return capi.make_input(**kw)
+
+    allow = {}
+    for a in args.allow_regress:
+        c, f, why = a.split(":", 2)
+        assert f in GATED and len(why) > 20, "--allow-regress wants case:figure:reason with a real reason"
+        allow[(c, f)] = why
+    cases = args.cases or sorted(os.path.basename(f)[6:-4] for f in glob.glob(os.path.join(G, "truth_*.npz")))
+    doc = json.load(open(RATCHET_FILE))
+    sha = csrc_sha()
+    if args.route is not None:
+        capi.set_option("route", args.route)
+    route = capi.get_option("route")
+    out_path = os.path.join(ROOT, "gpurun_out", "accuracy_ratchet.json")
+    failed = []
     for name in cases:
         t = np.load(os.path.join(G, "truth_" + name + ".npz")); g = np.load(os.path.join(G, name + ".npz"))
         Eref = g["E"]
@@ -48,12 +102,17 @@ def main():
             sel = t["chan"] == l
             per.append(truth_stats(E[l], Eref[l], t["idx"][sel], t["hi"][sel]))
         a = aggregate_stats(per)
-        a["kind_grid"] = int(inp_of(name).kind_grid)
-        a["nfun"] = int(prob.nfun)
-        out["cases"][name] = a
-        print(name, a, flush=True)
+        entry = doc["cases"].setdefault(name, {})
+        entry.update({"channels": a["channels"], "n_truth": a["n_truth"], "kind_grid": int(inp_of(name).kind_grid), "nfun": int(prob.nfun)})
+        left = merge(entry, a, sha, allow, name, route)
+        print(name, {k: a[k] for k in ("max_abs", "near_zero", "n_beyond", "worst_rel")}, "best", entry["best"],
+              ("OVER THE GATE: " + ", ".join("%s %.4g > %.4g" % v for v in left)) if left else "", flush=True)
+        failed += [(name,) + v for v in left]
         prob.close()
-        json.dump(out, open(old, "w"), indent=1, sort_keys=True)
+        json.dump(doc, open(out_path, "w"), indent=1, sort_keys=True)
+    if failed:
+        print("make_ratchet: %d figure(s) over the committed gate; `best` was not raised (see --allow-regress)" % len(failed))
+        sys.exit(1)
 
 
 if __name__ == "__main__":
