@@ -32,7 +32,7 @@ class Sizes(C.Structure):
 
 
 EXPORTS = ["bspatom_input_defaults", "bspatom_device_count", "bspatom_host_setup", "bspatom_problem_create", "bspatom_problem_destroy",
-           "bspatom_problem_sizes", "bspatom_problem_grid", "bspatom_assemble", "bspatom_solve", "bspatom_solve_dev",
+           "bspatom_problem_sizes", "bspatom_problem_grid", "bspatom_problem_route", "bspatom_assemble", "bspatom_solve", "bspatom_solve_dev",
            "bspatom_eigvec", "bspatom_eigvecs", "bspatom_dipole_bands", "bspatom_dipole_elements", "bspatom_write_wf", "bspatom_last_timing", "bsp_dsygv_", "bspatom_stage_gemm",
            "bspatom_stage_standard_form", "bspatom_stage_sy2sb", "bspatom_stage_panel", "bspatom_stage_sb2st", "bspatom_stage_sb2sb", "bspatom_stage_bisect", "bspatom_stage_crawford",
            "bspatom_set_option", "bspatom_get_option", "bspatom_kernel_times", "bspatom_kernel_slot_name"]
@@ -56,6 +56,7 @@ def lib():
         L.bspatom_problem_destroy.restype = None
         L.bspatom_problem_sizes.argtypes = [vp, C.POINTER(Sizes)]
         L.bspatom_problem_grid.argtypes = [vp, vp, vp, vp, vp]
+        L.bspatom_problem_route.argtypes = [vp]
         L.bspatom_assemble.argtypes = [vp, i32, i32, vp, vp]
         L.bspatom_solve.argtypes = [vp, i32, i32, vp, vp]
         L.bspatom_solve_dev.argtypes = [vp, i32, i32, vp, vp]
@@ -190,6 +191,12 @@ class Problem:
         r = np.zeros(npts + 1); u = np.zeros(npts + 1)
         _chk(lib().bspatom_write_wf(self._h, _p(c), npts, _p(r), _p(u)), "bspatom_write_wf")
         return r, u
+
+    def route(self):
+        """2 = band route (csrc/crawford.hip), 1 = dense route: what solve() takes under the current switches"""
+        r = lib().bspatom_problem_route(self._h)
+        _chk(min(r, 0), "bspatom_problem_route")
+        return r
 
     def last_timing(self):
         ms = np.zeros(6)

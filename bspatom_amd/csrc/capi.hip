@@ -78,7 +78,7 @@ const OptName OPT_TABLE[] = {
     {"poison_c", "BSP_POISON_C", &Options::poison_c}, {"sb2sb_mfma", "BSP_SB2SB_MFMA", &Options::sb2sb_mfma},
     {"ktime", "BSP_KTIME", &Options::ktime}, {"tsqr_regcap", "BSP_TSQR_REGCAP", &Options::tsqr_regcap},
     {"tsqr_max_m", "BSP_TSQR_MAX_M", &Options::tsqr_max_m}, {"sb16_rows", "BSP_SB16_ROWS", &Options::sb16_rows},
-    {"route", "BSP_ROUTE", &Options::route},
+    {"route", "BSP_ROUTE", &Options::route}, {"cw_onediv", "BSP_CW_ONEDIV", &Options::cw_onediv},
 };
 }  // namespace
 
@@ -308,6 +308,12 @@ extern "C" int bspatom_problem_sizes(const bspatom_problem *p, bspatom_sizes *s)
     s->nbc1 = h.nbc1; s->nbc2 = h.nbc2; s->lmax = h.lmax; s->nintv_exp = h.nintv_exp;
     s->nintv_lin = h.nintv_lin; s->npad = p->npad;
     return BSP_OK;
+}
+
+extern "C" int bspatom_problem_route(const bspatom_problem *p)
+{
+    if (!p) return BSP_ERR_ARG;
+    return pipeline_route(p->hs.nfun, p->hs.k);
 }
 
 extern "C" int bspatom_problem_grid(const bspatom_problem *p, double *rt, double *aind, double *xg, double *wg)

@@ -74,9 +74,17 @@ __device__ __forceinline__ double cw_lane(double x)
 }
 
 // One step of the RQ factorisation of X = [F E] (8 x 16; x0: rows 0-3, x1: rows 4-7; lane (g, c) holds rows g and 4 + g at
-// column c): the reflector H = I - tau v v^T on columns 0 .. 8 + I that leaves row I as (0 .. 0, beta, *), applied to the rows
-// above it and accumulated into Q <- Q H.  Rows below I have zeros wherever v has not and are left as they are.
-template <int I>
+// column c): the reflector H = I - t u u^T on columns 0 .. 8 + I that leaves row I as (0 .. 0, beta, *), applied to the rows
+// above it.  u is NOT scaled to a unit last component: u = (x_0 .. x_{LEN-1}, alpha - beta), t = -1 / (beta (alpha - beta))
+// = 2 / u^T u -- one division per reflector instead of two, no multiplication of the vector (ONEDIV; an A/B switch: 4 ms faster,
+// and its rounding moves the accuracy figures by what separates any two stable routes -- enough to trip the ratchet on one case,
+// so LAPACK's dlarfg form with two divisions is the default).  Rows below I have zeros wherever u
+// has not and are left as they are.  The reflector is accumulated into Q <- Q H.
+// (Measured and not kept, profiles/r04_experiments.txt: Q built after the loop by left multiplications H_i Q with the row vector
+// u_i^T Q on the matrix cores -- 4 MFMAs instead of four 16-lane sums per reflector, 24 % fewer instructions -- is SLOWER, 59.8
+// against 56.2 ms for the stage: on gfx950 an fp64 MFMA costs what its 1024 multiply-adds cost on the vector pipe, and a row
+// vector replicated over 16 rows wastes 15 / 16 of them.)
+template <int I, bool ONEDIV>
 __device__ __forceinline__ void rq_step(double &x0, double &x1, double (&q)[4], const int g, const int c)
 {
     constexpr int LEN = CB + I, GI = I & 3;
@@ -84,27 +92,29 @@ __device__ __forceinline__ void rq_step(double &x0, double &x1, double (&q)[4], 
     const double xi = cw_bperm(xr, GI * 16 + c);                       // row I in every DPP row
     const double sig = cw_rowsum(c < LEN ? xi * xi : 0.0);
     const double alpha = cw_lane<LEN>(xi);
-    const double a2s = alpha * alpha + sig;
+    const double a2s = fma(alpha, alpha, sig);
     const bool ok = (a2s > 1e-280) && (sig != 0.0);                    // nothing (numerically) left of the pivot: H = I
     const double nrm = sqrt(ok ? a2s : 1.0);
     const double bt = (alpha >= 0.0) ? -nrm : nrm;
-    const double tau = ok ? (bt - alpha) / bt : 0.0;
-    const double scale = ok ? 1.0 / (alpha - bt) : 0.0;
+    const double amb = alpha - bt;                                     // |alpha| + nrm with alpha's sign: no cancellation
+    // ONEDIV = false: LAPACK's form (dlarfg), u scaled to a unit last component, tau = (beta - alpha) / beta: two divisions
+    const double sc = ONEDIV ? 1.0 : (ok ? 1.0 / amb : 0.0);
+    const double t = ok ? (ONEDIV ? -1.0 / (bt * amb) : (bt - alpha) / bt) : 0.0;
     const double beta = ok ? bt : alpha;
-    const double v = (c < LEN) ? xi * scale : ((c == LEN) ? 1.0 : 0.0);
+    const double u = (c < LEN) ? (ONEDIV ? xi : xi * sc) : ((c == LEN) ? (ONEDIV ? amb : 1.0) : 0.0);
     if (I > 0) {
-        const double w0 = cw_rowsum(x0 * v);
-        x0 = fma(-tau * w0, v, x0);
+        const double w0 = cw_rowsum(x0 * u);
+        x0 = fma(-t * w0, u, x0);
     }
     if (I > 4) {
-        const double w1 = cw_rowsum(x1 * v);
-        x1 = fma(-tau * w1, v, x1);
+        const double w1 = cw_rowsum(x1 * u);
+        x1 = fma(-t * w1, u, x1);
     }
     if (g == GI) xr = (c < LEN) ? 0.0 : ((c == LEN) ? beta : xr);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const double wq = cw_rowsum(q[r] * v);
-        q[r] = fma(-tau * wq, v, q[r]);
+        const double wq = cw_rowsum(q[r] * u);
+        q[r] = fma(-t * wq, u, q[r]);
     }
 }
 
@@ -115,6 +125,7 @@ __device__ __forceinline__ double4_t cw_mfma(double a, double b, double4_t acc)
 
 // Wavefront t: chase items j = jlo .. jlo + nch - 1 (s = t - 2 j, p = j - 2 - s) and, if jel > 0, the elimination of step jel
 // (window (jel - 1, jel)).  grid = (ceil(items / 4), channels), one wave per item.
+template <bool ONEDIV>
 __global__ __launch_bounds__(256) void crawford_item_kernel(int N, int t, int jlo, int nch, int jel,
                                                            const double *__restrict__ Qel, double *Dall, double *Eall, double *Gall)
 {
@@ -157,14 +168,14 @@ __global__ __launch_bounds__(256) void crawford_item_kernel(int N, int t, int jl
         x1 = src[(4 + g) * CB];
 #pragma unroll
         for (int r = 0; r < 4; ++r) q[r] = (4 * r + g == c) ? 1.0 : 0.0;
-        rq_step<7>(x0, x1, q, g, c);
-        rq_step<6>(x0, x1, q, g, c);
-        rq_step<5>(x0, x1, q, g, c);
-        rq_step<4>(x0, x1, q, g, c);
-        rq_step<3>(x0, x1, q, g, c);
-        rq_step<2>(x0, x1, q, g, c);
-        rq_step<1>(x0, x1, q, g, c);
-        rq_step<0>(x0, x1, q, g, c);
+        rq_step<7, ONEDIV>(x0, x1, q, g, c);
+        rq_step<6, ONEDIV>(x0, x1, q, g, c);
+        rq_step<5, ONEDIV>(x0, x1, q, g, c);
+        rq_step<4, ONEDIV>(x0, x1, q, g, c);
+        rq_step<3, ONEDIV>(x0, x1, q, g, c);
+        rq_step<2, ONEDIV>(x0, x1, q, g, c);
+        rq_step<1, ONEDIV>(x0, x1, q, g, c);
+        rq_step<0, ONEDIV>(x0, x1, q, g, c);
     } else {
         const double *Qj = Qel + (size_t)j * 256;
 #pragma unroll
@@ -380,8 +391,12 @@ int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const doubl
         const int nch = (jhi >= jlo && jlo >= 2) ? jhi - jlo + 1 : 0;
         const int items = nch + (jel ? 1 : 0);
         if (items == 0) continue;
-        hipLaunchKernelGGL(crawford_item_kernel, dim3((items + 3) / 4, nl), dim3(256), 0, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E,
-                           w.G);
+        if (opts().cw_onediv)
+            hipLaunchKernelGGL(crawford_item_kernel<true>, dim3((items + 3) / 4, nl), dim3(256), 0, st, N, t, jlo, nch, jel, w.Qel, w.D,
+                               w.E, w.G);
+        else
+            hipLaunchKernelGGL(crawford_item_kernel<false>, dim3((items + 3) / 4, nl), dim3(256), 0, st, N, t, jlo, nch, jel, w.Qel, w.D,
+                               w.E, w.G);
     }
     BSP_HIP(hipGetLastError());
     hipLaunchKernelGGL(crawford_band_kernel, dim3((npad * 32 + 255) / 256, nl), dim3(256), 0, st, n, npad, N, w.D, w.E, d_AB);

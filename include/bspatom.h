@@ -66,6 +66,9 @@ int bspatom_host_setup(const bspatom_input *in, bspatom_sizes *s, double *rt, do
 int bspatom_problem_create(const bspatom_input *in, int device, bspatom_problem **out);
 void bspatom_problem_destroy(bspatom_problem *p);
 int bspatom_problem_sizes(const bspatom_problem *p, bspatom_sizes *s);
+/* The route bspatom_solve takes for this problem under the current switches (BSP_ROUTE / option "route"): 2 = band route
+ * (csrc/crawford.hip: the pencil stays banded; k - 1 <= 8), 1 = dense route (standard form, two-stage tridiagonalisation). */
+int bspatom_problem_route(const bspatom_problem *p);
 /* Host copies of rt[nkp], aind[2*nfun] (column-major Aind(nfun,2)), xg[ka], wg[ka]; any may be NULL. */
 int bspatom_problem_grid(const bspatom_problem *p, double *rt, double *aind, double *xg, double *wg);
 

@@ -14,6 +14,39 @@ pytestmark = pytest.mark.gpu
 from bspatom_amd import capi
 
 
+class _Options:
+    """Flip run-time switches of the library for one test and restore them."""
+    def __init__(self, **kw):
+        self.kw = kw
+    def __enter__(self):
+        self.old = {k: capi.get_option(k) for k in self.kw}
+        for k, v in self.kw.items():
+            capi.set_option(k, v)
+        return self
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            capi.set_option(k, v)
+
+
+
+# Two routes lead from the bands to the tridiagonal matrix (csrc/capi.hip::pipeline_route, BSP_ROUTE): the BAND route
+# (crawford.hip, the default wherever the pencil's half-width is at most 8) and the DENSE route (standard form, sy2sb, two-step
+# bulge chasing: north_star's letter, and the only one for k > 9).  The parity tests at the BASELINE sizes run both; tests of
+# the dense route's own switches force it.
+ROUTES = [pytest.param(0, id="default-route"), pytest.param(1, id="dense-route")]
+DENSE_ROUTE_TESTS = {"test_sb2st_fallback_paths", "test_two_step_band_reduction_route", "test_panel_qr_first_kernel_matches_second",
+                     "test_reduction_reads_only_the_valid_blocks_of_C", "test_sb2st_handoff_under_uneven_load"}
+
+
+@pytest.fixture(autouse=True)
+def _dense_route_where_the_test_is_about_it(request):
+    if getattr(request.node, "originalname", request.node.name) in DENSE_ROUTE_TESTS:
+        with _Options(route=1):
+            yield
+    else:
+        yield
+
+
 def figures(E, Eref):
     lam = np.max(np.abs(Eref))
     return np.max(np.abs(E - Eref) / np.abs(Eref)), np.max(np.abs(E - Eref)) / lam
@@ -76,13 +109,17 @@ def full_size_bar(E, Eref, tag, truth=None, judge=None, stats=None):
     assert ng_above_noise <= nr + 1, msg
 
 
+@pytest.mark.parametrize("route", ROUTES)
 @pytest.mark.parametrize("name", SMALL_CASES + ["lin1024", "c2_2048", "c3_1024_l31", "c5_1024_k11"])
-def test_spectra_vs_reference(name):
+def test_spectra_vs_reference(name, route):
     g = load_golden(name)
     inp = input_from_case(name)
     prob = capi.Problem(inp)
+    if route == 1 and prob.route() == 1:
+        pytest.skip("the default route of this case is the dense one already")
     lmax = prob.lmax
-    E, info = prob.solve(0, lmax + 1)
+    with _Options(route=route):
+        E, info = prob.solve(0, lmax + 1)
     assert np.all(info == 0)
     lin = inp.kind_grid == 0
     truth = load_truth(name) if os.path.exists(os.path.join(ROOT, "tests", "golden", "truth_%s.npz" % name)) else {}
@@ -94,7 +131,7 @@ def test_spectra_vs_reference(name):
         if lin:
             full_size_bar(E[l], g["E"][l], "  bar %s l=%d" % (name, l), truth.get(l), stats=stats)
     if stats:
-        note(ratchet_check(name, stats))
+        note(ratchet_check(name, stats, route=prob.route() if route == 0 else route))
     prob.close()
 
 
@@ -304,11 +341,13 @@ def test_python_host_outputs(tmp_path):
     assert "Program Finished!" in text
 
 
-def test_c4_channels_at_full_size():
+@pytest.mark.parametrize("route", ROUTES)
+def test_c4_channels_at_full_size(route):
     """BASELINE configs[3] size (n=4096, k=9, rb=800): channels l=0,1 against the reference's spectra."""
     g = load_golden("c4_4096")
     prob = capi.Problem(input_from_case("c4_4096"))
-    E, info = prob.solve(0, 2)
+    with _Options(route=route):
+        E, info = prob.solve(0, 2)
     assert np.all(info == 0)
     truth = load_truth("c4_4096")
     stats = []
@@ -318,7 +357,7 @@ def test_c4_channels_at_full_size():
         nq = np.arange(1, 11) + l
         exact = -0.5 / nq ** 2
         assert np.max(np.abs(E[l, :10] - exact)) <= np.max(np.abs(g["E"][l, :10] - exact)) + 1e-13
-    note(ratchet_check("c4_4096", stats))
+    note(ratchet_check("c4_4096", stats, route=route or 2))
     prob.close()
 
 
@@ -341,13 +380,15 @@ def test_full_size_properties_128_channels():
     prob.close()
 
 
-def test_spectra_do_not_depend_on_the_batch_size():
+@pytest.mark.parametrize("route", ROUTES)
+def test_spectra_do_not_depend_on_the_batch_size(route):
     """BASELINE configs[3] on N GPUs gives every GPU 128 / N channels: the spectrum of a channel must not depend on how many
     channels are solved with it.  l = 0 .. 15 solved as a batch of 16 (what each of 8 GPUs sees), of 32, and as part of the
     full batch of 128: bit-identical.  Everything that is chosen by batch size keeps the arithmetic: channel groups and update
     slices of sy2sb, the rings of the bulge chasing; the panel factorisation is chosen by the panel's row count alone and the
     bisection has one workgroup shape (rounds 1-2 picked it by batch size, which changed the last bits)."""
     prob = capi.Problem(input_from_case("c4_4096", l_fin=127))
+    capi.set_option("route", route)
     E128, info = prob.solve(0, 128)
     assert np.all(info == 0)
     for nb in (16, 32, 1):
@@ -357,19 +398,22 @@ def test_spectra_do_not_depend_on_the_batch_size():
             nb, np.max(np.abs(Eb - E128[:nb]) / np.abs(E128[:nb])))
     # a block that does not start at l = 0 (rank r of N owns l = r * 128 / N ..)
     Eb, info = prob.solve(48, 16)
+    capi.set_option("route", 0)
     assert np.array_equal(Eb, E128[48:64])
     prob.close()
 
 
-def test_full_size_batch_is_deterministic():
+@pytest.mark.parametrize("route", ROUTES)
+def test_full_size_batch_is_deterministic(route):
     """The paired bulge-chasing workgroups synchronise through published progress words; the arithmetic and its
     order do not depend on their timing, so repeated solves must agree bit for bit (a race shows up as a difference)."""
     prob = capi.Problem(input_from_case("c4_4096", l_fin=127))
-    E0, info = prob.solve(0, 128)
-    assert np.all(info == 0)
-    for _ in range(3):
-        E, info = prob.solve(0, 128)
-        assert np.array_equal(E, E0)
+    with _Options(route=route):
+        E0, info = prob.solve(0, 128)
+        assert np.all(info == 0)
+        for _ in range(3):
+            E, info = prob.solve(0, 128)
+            assert np.array_equal(E, E0)
     prob.close()
 
 
@@ -537,20 +581,6 @@ def test_transition_amplitudes_vs_reference(name):
 
 
 # ---- round 2: the paths no test executed before (configs_untested, weak 2/8, missing 3-5) -----------------
-class _Options:
-    """Flip run-time switches of the library for one test and restore them."""
-    def __init__(self, **kw):
-        self.kw = kw
-    def __enter__(self):
-        self.old = {k: capi.get_option(k) for k in self.kw}
-        for k, v in self.kw.items():
-            capi.set_option(k, v)
-        return self
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            capi.set_option(k, v)
-
-
 def test_c5_at_full_size():
     """BASELINE configs[4] AT ITS REAL SIZE: Rogers screened Coulomb (KIND_POT=1, Zatom=20), N_bsp=8192, k=11, one
     channel, against the compiled reference's spectrum (tests/golden/c5_8192.npz, ~15 min of LAPACK DSYGV in the build
@@ -565,12 +595,13 @@ def test_c5_at_full_size():
     note("c5_8192 timing %s" % prob.last_timing())
     stats = []
     full_size_bar(E[0], g["E"][0], "solve c5_8192 l=0", load_truth("c5_8192")[0], stats=stats)
-    note(ratchet_check("c5_8192", stats))
+    note(ratchet_check("c5_8192", stats, route=1))
     prob.close()
 
 
+@pytest.mark.parametrize("route", ROUTES)
 @pytest.mark.parametrize("name", ["bc1_2048", "sf2048", "exp2048", "explin2048"])
-def test_variants_at_scale(name):
+def test_variants_at_scale(name, route):
     """SURVEY 8(f).4 at scale (nfun ~ 2048): KIND_BC=1 (first/last B-spline kept, ReadInputs.f90:42-45), the Simons-Fues
     l-dependent Bl/r^2 term (KIND_POT=2, matrices.f90:151; l = 0..4 so that Bl(l>3) = 0 is exercised), and the
     exponential / exponential-linear knot sequences (grid.f90:35-61; explin resizes nfun to 2456).  Linear grids: the
@@ -582,7 +613,8 @@ def test_variants_at_scale(name):
     prob = capi.Problem(inp)
     nch = g["E"].shape[0]
     assert prob.nfun == g["E"].shape[1]
-    E, info = prob.solve(0, nch)
+    with _Options(route=route):
+        E, info = prob.solve(0, nch)
     assert np.all(info == 0)
     truth = load_truth(name)
     stats = []
@@ -601,8 +633,47 @@ def test_variants_at_scale(name):
                     np.max(er / np.abs(tru)), er.max(), er.max() / (np.finfo(float).eps * lam)))
             assert np.max(np.abs(E[l] - g["E"][l])) <= 1e-13 * lam
             assert np.all(eg <= 1e-10 * np.abs(tru) + 2.0 * np.maximum(er, np.max(er[near])))
-    note(ratchet_check(name, stats, linear=inp.kind_grid == 0))
+    note(ratchet_check(name, stats, linear=inp.kind_grid == 0, route=route or 2))
     prob.close()
+
+
+def test_band_route_properties():
+    """The band route (csrc/crawford.hip + the band-16 chase) on 12 channels at n = 1024 and on the padded sizes: the same
+    spectra as the dense route to rounding; bit-identical when repeated, for every ring size of the band-16 chase and both
+    fallbacks of its handshake, for the first layout of that chase to rounding; and whatever the batch a channel is solved in."""
+    prob = capi.Problem(input_from_case("c3_1024_l31"))
+    assert prob.route() == 2
+    with _Options(route=1):
+        Ed, info = prob.solve(0, 12)
+    assert np.all(info == 0)
+    E0, info = prob.solve(0, 12)
+    assert np.all(info == 0)
+    lam = np.max(np.abs(Ed))
+    note("band route vs dense route, 12 channels n=1024: normwise %.2e, worst relative %.2e" % (
+        np.max(np.abs(E0 - Ed)) / lam, np.max(np.abs(E0 - Ed) / np.abs(Ed))))
+    assert np.max(np.abs(E0 - Ed)) <= 1e-13 * lam
+    for kw in [dict(), dict(sb2st_ring=8), dict(sb2st_ring=4), dict(sb2st_ring=2), dict(sb2st_ring=1), dict(sb2st_force_abort=1),
+               dict(sb2st_force_abort=2)]:
+        with _Options(**kw):
+            E, info = prob.solve(0, 12)
+        assert np.all(info == 0), kw
+        assert np.array_equal(E, E0), (kw, np.max(np.abs(E - E0)) / lam)
+    with _Options(sb16_rows=0):
+        E, info = prob.solve(0, 12)
+    assert np.max(np.abs(E - E0)) <= 1e-13 * lam
+    E1, _ = prob.solve(0, 1)
+    E5, _ = prob.solve(7, 5)
+    assert np.array_equal(E1, E0[:1]) and np.array_equal(E5, E0[7:12])
+    prob.close()
+    for name in ("lin256", "n128", "c1_lin", "bc10", "ka_ra"):          # sizes that are not multiples of 8, few blocks
+        prob = capi.Problem(input_from_case(name))
+        nl = prob.lmax + 1
+        with _Options(route=1):
+            Ed, _ = prob.solve(0, nl)
+        Eb, info = prob.solve(0, nl)
+        assert prob.route() == 2 and np.all(info == 0)
+        assert np.max(np.abs(Eb - Ed)) <= 1e-13 * np.max(np.abs(Ed)), name
+        prob.close()
 
 
 def test_sb2st_fallback_paths():
@@ -1092,21 +1163,23 @@ def test_sb2st_handoff_under_uneven_load(tmp_path):
     prob.close()
 
 
-def test_c3_at_full_size_all_channels():
+@pytest.mark.parametrize("route", ROUTES)
+def test_c3_at_full_size_all_channels(route):
     """BASELINE configs[2] AT ITS REAL SIZE: Hydrogen l = 0..31 batched, N_bsp = 2048, k = 9 -- every one of the 32 channels
     against the spectra the reference PROGRAM wrote (oracle/_ref/Bsp_Atom_ref.x, tests/golden/c3_2048_l31.npz: its Enl.dat)
     and against the 113-bit truth of 39 eigenvalues per channel; wf_n0.dat against the reference's file."""
     g = load_golden("c3_2048_l31")
     inp = input_from_case("c3_2048_l31")
     prob = capi.Problem(inp)
-    E, info = prob.solve(0, 32)
+    with _Options(route=route):
+        E, info = prob.solve(0, 32)
     assert np.all(info == 0)
     note("c3_2048_l31 timing %s -> %.1f eigensolves/s" % (prob.last_timing(), 32e3 / prob.last_timing()["total"]))
     truth = load_truth("c3_2048_l31")
     stats = []
     for l in range(32):
         full_size_bar(E[l], g["E"][l], "solve c3_2048_l31 l=%d" % l, truth[l], stats=stats)
-    note(ratchet_check("c3_2048_l31", stats))
+    note(ratchet_check("c3_2048_l31", stats, route=route or 2))
     c = prob.eigvec(inp.l_ini, inp.n0_ini)
     r, u = prob.write_wf(c)
     rows = g["wf_rows"]; idx = g["wf_idx"]
@@ -1115,7 +1188,8 @@ def test_c3_at_full_size_all_channels():
     prob.close()
 
 
-def test_c4_all_128_channels_vs_reference():
+@pytest.mark.parametrize("route", ROUTES)
+def test_c4_all_128_channels_vs_reference(route):
     """BASELINE configs[3], THE BENCH WORKLOAD, every channel: Hydrogen l = 0..127, N_bsp = 4096, k = 9 against the spectra the
     reference PROGRAM wrote for all 128 channels (tests/golden/c4_4096_l127.npz: ~3.75 h of LAPACK DSYGV on 8 cores in the build
     container) and the 113-bit truth: stored for the eigenvalues around zero of every channel (the set is grown until the
@@ -1126,7 +1200,8 @@ def test_c4_all_128_channels_vs_reference():
     from bspatom_amd.namelist import read_namelists
     g = load_golden("c4_4096_l127")
     prob = capi.Problem(input_from_case("c4_4096_l127"))
-    E, info = prob.solve(0, 128)
+    with _Options(route=route):
+        E, info = prob.solve(0, 128)
     assert np.all(info == 0)
     truth = load_truth("c4_4096_l127")
     bands = {}
@@ -1148,7 +1223,7 @@ def test_c4_all_128_channels_vs_reference():
     for l in range(128):
         full_size_bar(E[l], g["E"][l], "solve c4_4096_l127 l=%d" % l, truth[l], judge_for(l), stats=stats)
     # the direct bar: round 2 measured 57 eigenvalues of 524 288 beyond 1e-10 relative of the truth, worst 3.5e-9
-    note(ratchet_check("c4_4096_l127", stats))
+    note(ratchet_check("c4_4096_l127", stats, route=route or 2))
     prob.close()
 
 

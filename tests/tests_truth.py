@@ -56,9 +56,10 @@ def aggregate_stats(per_channel):
             "n_truth": sum(s["n_truth"] for s in per_channel), "channels": len(per_channel)}
 
 
-def ratchet_gate(entry, fig):
-    """the bar of one gated figure of one case: an explicit override if the JSON carries one, else 2 x best with its floor"""
-    ov = entry.get("override", {}).get(fig)
+def ratchet_gate(entry, fig, route=None):
+    """the bar of one gated figure of one case: an explicit override if the JSON carries one for this route (1 dense, 2 band),
+    else 2 x best with its floor"""
+    ov = entry.get("override", {}).get("route%s" % route, {}).get(fig)
     if ov is not None:
         return float(ov["bar"])
     best = entry["best"][fig]
@@ -67,22 +68,23 @@ def ratchet_gate(entry, fig):
     return max(RATCHET_FACTOR * best, RATCHET_FLOOR_NEAR if fig == "near_zero" else RATCHET_FLOOR_ABS)
 
 
-def ratchet_violations(entry, a, linear=True):
+def ratchet_violations(entry, a, linear=True, route=None):
     """gated figures of the measured aggregate `a` that exceed their bars: list of (figure, value, bar)"""
     figs = GATED if linear else ("max_abs", "near_zero")       # grids with an exponential part: relative errors next to zero are
     out = []                                                   # not meaningful (SURVEY 8d), absolute ones are
     for fig in figs:
         if entry["best"].get(fig) is None:
             continue                                           # no measurement of this figure yet (make_ratchet.py fills it)
-        bar = ratchet_gate(entry, fig)
+        bar = ratchet_gate(entry, fig, route)
         if a[fig] > bar:
             out.append((fig, a[fig], bar))
     return out
 
 
-def ratchet_check(case, per_channel, linear=True):
+def ratchet_check(case, per_channel, linear=True, route=None):
     """Assert the aggregated figures of `case` (list of truth_stats, one per channel, ALL its channels) against the committed
-    ratchet.  Returns the message that describes both."""
+    ratchet (`route`: the route the spectra were computed by, for the route-specific overrides).  Returns the message that
+    describes both."""
     import json
     assert os.path.exists(RATCHET_FILE), "tests/golden/accuracy_ratchet.json is missing: run tools/make_ratchet.py on the GPU box"
     R = json.load(open(RATCHET_FILE))["cases"]
@@ -93,6 +95,6 @@ def ratchet_check(case, per_channel, linear=True):
     msg = ("ratchet %s: max abs / (eps lam) %.4f (best %s), near zero %.4f (best %.4f), beyond 1e-10: %d (best %d); worst rel %.2e (not gated)"
            % (case, a["max_abs"], "%.4f" % b["max_abs"] if b.get("max_abs") is not None else "-", a["near_zero"], b["near_zero"],
               a["n_beyond"], b["n_beyond"], a["worst_rel"]))
-    bad = ratchet_violations(r, a, linear)
+    bad = ratchet_violations(r, a, linear, route)
     assert not bad, msg + " -- over the bar: " + ", ".join("%s %.4g > %.4g" % v for v in bad)
     return msg

@@ -38,22 +38,23 @@ def rq_step(I, x0, x1, q):
     ok = (a2s > 1e-280) & (sig != 0.0)
     nrm = np.sqrt(np.where(ok, a2s, 1.0))
     bt = np.where(alpha >= 0, -nrm, nrm)
+    amb = alpha - bt
     with np.errstate(all="ignore"):
-        tau = np.where(ok, (bt - alpha) / bt, 0.0)
-        scale = np.where(ok, 1.0 / (alpha - bt), 0.0)
+        t = np.where(ok, (bt - alpha) / bt, 0.0)
+        sc = np.where(ok, 1.0 / amb, 0.0)
     beta = np.where(ok, bt, alpha)
-    v = np.where(c < LEN, xi * scale, np.where(c == LEN, 1.0, 0.0))
+    u = np.where(c < LEN, xi * sc, np.where(c == LEN, 1.0, 0.0))
     if I > 0:
-        w0 = rowsum(x0 * v); x0 = x0 - tau * w0 * v
+        w0 = rowsum(x0 * u); x0 = x0 - t * w0 * u
     if I > 4:
-        w1 = rowsum(x1 * v); x1 = x1 - tau * w1 * v
+        w1 = rowsum(x1 * u); x1 = x1 - t * w1 * u
     xr = x0 if I < 4 else x1
     fixed = np.where(c < LEN, 0.0, np.where(c == LEN, beta, xr))
     xr = np.where(g == GI, fixed, xr)
     if I < 4: x0 = xr
     else: x1 = xr
     for r in range(4):
-        wq = rowsum(q[r] * v); q[r] = q[r] - tau * wq * v
+        wq = rowsum(q[r] * u); q[r] = q[r] - t * wq * u
     return x0, x1, q
 
 

@@ -41,20 +41,20 @@ def csrc_sha():
 def merge(entry, a, sha, allow, name, route):
     """fold the measurement `a` into the committed entry; returns the violated gates that were not allowed"""
     linear = entry.get("kind_grid", 0) == 0
-    bad = [] if not entry.get("best") else ratchet_violations(entry, a, linear)
+    bad = [] if not entry.get("best") else ratchet_violations(entry, a, linear, route)
     best = dict(entry.get("best") or {})
     for fig in GATED:
         old = best.get(fig)
         best[fig] = a[fig] if old is None else min(old, a[fig])
     entry["best"] = best
-    entry["last"] = {k: a[k] for k in ("worst_rel", "max_abs", "near_zero", "n_beyond")}
-    entry["last"]["csrc_sha16"] = sha
-    entry["last"]["route"] = route
+    last = {k: a[k] for k in ("worst_rel", "max_abs", "near_zero", "n_beyond")}
+    last["csrc_sha16"] = sha
+    entry.setdefault("last", {})["route%d" % route] = last     # per route: 1 dense, 2 band
     left = []
     for fig, val, bar in bad:
         why = allow.get((name, fig))
         if why:
-            entry.setdefault("override", {})[fig] = {"bar": (max(int(2 * val), val + 2) if fig == "n_beyond" else 2.0 * val),
+            entry.setdefault("override", {}).setdefault("route%d" % route, {})[fig] = {"bar": (max(int(2 * val), val + 2) if fig == "n_beyond" else 2.0 * val),
                                                      "measured": val, "gate_without_override": bar, "why": why, "csrc_sha16": sha}
         else:
             left.append((fig, val, bar))
@@ -66,6 +66,7 @@ def main():
     ap.add_argument("cases", nargs="*")
     ap.add_argument("--route", type=int, default=None, help="bspatom_set_option('route', N) for the measurement (default: the library's default route)")
     ap.add_argument("--allow-regress", action="append", default=[], metavar="case:figure:reason")
+    ap.add_argument("--base", default=RATCHET_FILE, help="the file to update (default: the committed one; a second pass of one GPU call names the first pass's output)")
     args = ap.parse_args()
     from bspatom_amd import capi
     from bspatom_amd.namelist import read_namelists
@@ -82,11 +83,10 @@ def main():
         assert f in GATED and len(why) > 20, "--allow-regress wants case:figure:reason with a real reason"
         allow[(c, f)] = why
     cases = args.cases or sorted(os.path.basename(f)[6:-4] for f in glob.glob(os.path.join(G, "truth_*.npz")))
-    doc = json.load(open(RATCHET_FILE))
+    doc = json.load(open(args.base))
     sha = csrc_sha()
     if args.route is not None:
         capi.set_option("route", args.route)
-    route = capi.get_option("route")
     out_path = os.path.join(ROOT, "gpurun_out", "accuracy_ratchet.json")
     failed = []
     for name in cases:
@@ -95,17 +95,26 @@ def main():
         chans = sorted(int(l) for l in np.unique(t["chan"]))
         nch = max(chans) + 1
         prob = capi.Problem(inp_of(name))
+        route = prob.route()                               # 1 dense, 2 band: what this case takes under the current switch
         E, info = prob.solve(0, nch)
         assert np.all(info == 0)
-        per = []
+        per, where = [], None
         for l in chans:
             sel = t["chan"] == l
             per.append(truth_stats(E[l], Eref[l], t["idx"][sel], t["hi"][sel]))
+            # the eigenvalue behind the case's near-zero figure, for the text of an override: value, absolute errors of both sides
+            idx, tru = t["idx"][sel], t["hi"][sel]
+            near = np.argsort(np.abs(tru))[:24]
+            eg = np.abs(E[l][idx] - tru)[near]
+            q = int(np.argmax(eg))
+            if where is None or per[-1]["near_zero"] >= where[0]:
+                where = (per[-1]["near_zero"], "l = %d, eigenvalue %d, E = %.6e: |E_gpu - truth| = %.2e, |E_ref - truth| = %.2e, lambda_max = %.3e"
+                         % (l, int(idx[near][q]) + 1, tru[near][q], eg[q], abs(Eref[l][idx[near][q]] - tru[near][q]), float(np.max(np.abs(Eref[l])))))
         a = aggregate_stats(per)
         entry = doc["cases"].setdefault(name, {})
         entry.update({"channels": a["channels"], "n_truth": a["n_truth"], "kind_grid": int(inp_of(name).kind_grid), "nfun": int(prob.nfun)})
         left = merge(entry, a, sha, allow, name, route)
-        print(name, {k: a[k] for k in ("max_abs", "near_zero", "n_beyond", "worst_rel")}, "best", entry["best"],
+        print(name, "route", route, {k: a[k] for k in ("max_abs", "near_zero", "n_beyond", "worst_rel")}, "best", entry["best"], "| near zero:", where[1],
               ("OVER THE GATE: " + ", ".join("%s %.4g > %.4g" % v for v in left)) if left else "", flush=True)
         failed += [(name,) + v for v in left]
         prob.close()
