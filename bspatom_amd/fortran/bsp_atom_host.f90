@@ -79,6 +79,47 @@
           INTEGER(C_INT), VALUE :: npts
           REAL(C_DOUBLE), INTENT(OUT) :: r(*), u(*)
         END FUNCTION
+!       the one exchange of the sharded run (include/bspatom.h, csrc/comm.hip): an RCCL all-gather of the ranks' records
+        INTEGER(C_INT) FUNCTION bspatom_run_token(buf, cap) BIND(C, NAME='bspatom_run_token')
+          IMPORT :: C_INT, C_CHAR
+          CHARACTER(KIND=C_CHAR) :: buf(*)
+          INTEGER(C_INT), VALUE :: cap
+        END FUNCTION
+        INTEGER(C_INT) FUNCTION bspatom_comm_create(rank, world, dir, comm) BIND(C, NAME='bspatom_comm_create')
+          IMPORT :: C_INT, C_CHAR, C_PTR
+          INTEGER(C_INT), VALUE :: rank, world
+          CHARACTER(KIND=C_CHAR), INTENT(IN) :: dir(*)
+          TYPE(C_PTR), INTENT(OUT) :: comm
+        END FUNCTION
+        INTEGER(C_INT) FUNCTION bspatom_comm_allgather(comm, send, recv, cnt) BIND(C, NAME='bspatom_comm_allgather')
+          IMPORT :: C_INT, C_PTR, C_DOUBLE, C_LONG
+          TYPE(C_PTR), VALUE :: comm
+          REAL(C_DOUBLE), INTENT(IN) :: send(*)
+          REAL(C_DOUBLE), INTENT(OUT) :: recv(*)
+          INTEGER(C_LONG), VALUE :: cnt
+        END FUNCTION
+        INTEGER(C_INT) FUNCTION bspatom_comm_collectives(comm) BIND(C, NAME='bspatom_comm_collectives')
+          IMPORT :: C_INT, C_PTR
+          TYPE(C_PTR), VALUE :: comm
+        END FUNCTION
+        SUBROUTINE bspatom_comm_destroy(comm) BIND(C, NAME='bspatom_comm_destroy')
+          IMPORT :: C_PTR
+          TYPE(C_PTR), VALUE :: comm
+        END SUBROUTINE
+!       libc, for the file exchange (the fallback when ranks share a GPU): no shell is forked from a process that holds a GPU
+        INTEGER(C_INT) FUNCTION c_rename(old, new) BIND(C, NAME='rename')
+          IMPORT :: C_INT, C_CHAR
+          CHARACTER(KIND=C_CHAR), INTENT(IN) :: old(*), new(*)
+        END FUNCTION
+        INTEGER(C_INT) FUNCTION c_mkdir(path, mode) BIND(C, NAME='mkdir')
+          IMPORT :: C_INT, C_CHAR
+          CHARACTER(KIND=C_CHAR), INTENT(IN) :: path(*)
+          INTEGER(C_INT), VALUE :: mode
+        END FUNCTION
+        INTEGER(C_INT) FUNCTION c_usleep(us) BIND(C, NAME='usleep')
+          IMPORT :: C_INT
+          INTEGER(C_INT), VALUE :: us
+        END FUNCTION
       END INTERFACE
       END MODULE BSPATOM_C
 
@@ -130,16 +171,25 @@
 !     reference's outputs, through files of a scratch directory (BSPATOM_XCHG, unique per run) -- the file boundary this
 !     program has anyway.  KIND_PI = 0 only, like the Python host's run_sharded.
       INTEGER :: rank, world, lrank, devid, l0s, nls, nbase, nrem, rr, owner, r0s, nlr, ios, tries
-      LOGICAL :: have_wf, ex
+      LOGICAL :: have_wf, ex, launched, use_rccl
       CHARACTER(LEN=512) :: envv, xdir, fname
       INTEGER(C_INT32_T), ALLOCATABLE :: infoall(:)
+      INTEGER(C_INT32_T) :: hdr(5)
+      INTEGER(C_INT32_T), PARAMETER :: XMAGIC = 1112756312                     ! 'BSPX'
+      CHARACTER(KIND=C_CHAR) :: tokc(128)
+      CHARACTER(LEN=128) :: token
+      TYPE(C_PTR) :: comm
+      INTEGER :: nmax, o
+      INTEGER(C_LONG) :: reclen
+      REAL(C_DOUBLE), ALLOCATABLE :: sbuf(:), rbuf(:)
 
       rank = 0; world = 1; lrank = 0
       CALL GET_ENVIRONMENT_VARIABLE('WORLD_SIZE', envv, STATUS=ios)
       IF( ios == 0 ) READ(envv,*,IOSTAT=ios) world
       IF( world < 1 ) world = 1
+      CALL GET_ENVIRONMENT_VARIABLE('RANK', envv, STATUS=ios)
+      launched = ( ios == 0 .AND. LEN_TRIM(envv) > 0 )                         ! under a launcher, also at world size 1
       IF( world > 1 ) THEN
-        CALL GET_ENVIRONMENT_VARIABLE('RANK', envv, STATUS=ios)
         IF( ios == 0 ) READ(envv,*,IOSTAT=ios) rank
         CALL GET_ENVIRONMENT_VARIABLE('LOCAL_RANK', envv, STATUS=ios)
         IF( ios == 0 ) READ(envv,*,IOSTAT=ios) lrank
@@ -197,6 +247,36 @@
       IF( rc /= 0 ) THEN
         WRITE(6,*) 'bsp_atom_host: bspatom_problem_create failed, code ', rc
         STOP 1
+      END IF
+!     Sharded run (or any run under a launcher): the spectra travel ONCE, at the end, as an RCCL all-gather of one record per rank
+!     (csrc/comm.hip).  The communicator is created now, before anything is solved.  Ranks that share a GPU (more ranks than
+!     devices: a test box) and BSPATOM_XCHG_MODE=files use stream files in the exchange directory instead; their names carry the
+!     token of this launch (launcher pid + start time), so a file another run left behind is never taken for this run's.
+      use_rccl = .FALSE.; comm = C_NULL_PTR; token = ' '
+      IF( world > 1 .OR. ( launched .AND. KIND_PI == 0 ) ) THEN
+        xdir = '.bspatom_xchg'
+        CALL GET_ENVIRONMENT_VARIABLE('BSPATOM_XCHG', envv, STATUS=ios)
+        IF( ios == 0 .AND. LEN_TRIM(envv) > 0 ) xdir = envv
+        rc = c_mkdir(TRIM(xdir)//C_NULL_CHAR, INT(O'777',C_INT))               ! exists already: fine
+        rc = bspatom_run_token(tokc, 128_C_INT)
+        IF( rc /= 0 ) THEN
+          WRITE(0,*) 'bsp_atom_host: no run token, code ', rc
+          STOP 1
+        END IF
+        DO i = 1, 128
+          IF( tokc(i) == C_NULL_CHAR ) EXIT
+          token(i:i) = tokc(i)
+        END DO
+        CALL GET_ENVIRONMENT_VARIABLE('BSPATOM_XCHG_MODE', envv, STATUS=ios)
+        IF( .NOT. ( ios == 0 .AND. TRIM(envv) == 'files' ) ) THEN
+          rc = bspatom_comm_create(INT(rank,C_INT), INT(world,C_INT), TRIM(xdir)//C_NULL_CHAR, comm)
+          IF( rc == 0 ) THEN
+            use_rccl = .TRUE.
+          ELSE IF( rc /= -5 ) THEN                                             ! -5: ranks share a GPU, or no librccl: files
+            WRITE(0,*) 'bsp_atom_host: bspatom_comm_create failed, code ', rc
+            STOP 1
+          END IF
+        END IF
       END IF
       rc = bspatom_problem_sizes(prob, sz)
 !     ---- what READ_INPUTS prints (ReadInputs.f90:54,67,71,93,127,186-202,222,236-271), in its order ----
@@ -328,6 +408,7 @@
       ALLOCATE( En(nfun*(lmax+1)), info(lmax+1), ci(nfun) )
       have_wf = .FALSE.
       IF( world == 1 ) THEN
+        nbase = lmax + 1; nrem = 0; l0s = 0; nls = lmax + 1; owner = 0
         rc = bspatom_solve(prob, 0_C_INT, INT(lmax+1,C_INT), En, info)
       ELSE
 !       this rank's block of channels, the static partition of bspatom_amd/parallel.py::channel_range
@@ -347,15 +428,7 @@
         WRITE(0,*) 'bsp_atom_host: bspatom_solve failed, code ', rc
         STOP 1
       END IF
-      IF( world > 1 ) THEN
-!       default: a directory under the working directory that carries the launcher's rendezvous port (the same for all
-!       ranks of a run, different for runs that overlap in time)
-        xdir = '.bspatom_xchg'
-        CALL GET_ENVIRONMENT_VARIABLE('MASTER_PORT', envv, STATUS=ios)
-        IF( ios == 0 .AND. LEN_TRIM(envv) > 0 ) xdir = '.bspatom_xchg.'//TRIM(envv)
-        CALL GET_ENVIRONMENT_VARIABLE('BSPATOM_XCHG', envv, STATUS=ios)
-        IF( ios == 0 .AND. LEN_TRIM(envv) > 0 ) xdir = envv
-        CALL EXECUTE_COMMAND_LINE('mkdir -p '//TRIM(xdir))
+      IF( world > 1 .OR. use_rccl ) THEN
         npts = 10000
         IF( rank == owner ) THEN                          ! the consumed eigenvector and its WRITE_WF table, by the rank that solved l_ini
           ALLOCATE( r(0:npts), u(0:npts) )
@@ -368,11 +441,63 @@
           END IF
           have_wf = .TRUE.
         END IF
+      END IF
+      IF( use_rccl ) THEN
+!       one record per rank: l0, nl, wf flag | info(nmax) | En(nfun, nmax) | r(0:npts), u(0:npts); all-gathered, rank 0 unpacks
+        nmax = nbase; IF( nrem > 0 ) nmax = nbase + 1
+        IF( world == 1 ) THEN
+          nmax = lmax + 1; l0s = 0; nls = lmax + 1
+        END IF
+        reclen = 3 + nmax + INT(nmax,C_LONG)*nfun + 2*(npts+1)
+        ALLOCATE( sbuf(reclen), rbuf(reclen*world) )
+        sbuf = 0.D0
+        sbuf(1) = l0s; sbuf(2) = nls; IF( have_wf ) sbuf(3) = 1.D0
+        IF( nls > 0 ) THEN
+          sbuf(4:3+nls) = info(l0s+1:l0s+nls)
+          sbuf(4+nmax:3+nmax+nls*nfun) = En(l0s*nfun+1:(l0s+nls)*nfun)
+        END IF
+        o = 3 + nmax + nmax*nfun
+        IF( have_wf ) THEN
+          sbuf(o+1:o+npts+1) = r(0:npts); sbuf(o+npts+2:o+2*npts+2) = u(0:npts)
+        END IF
+        rc = bspatom_comm_allgather(comm, sbuf, rbuf, reclen)
+        IF( rc /= 0 ) THEN
+          WRITE(0,*) 'bsp_atom_host: the all-gather of the spectra failed, code ', rc
+          STOP 1
+        END IF
+        IF( rank > 0 ) THEN
+          CALL bspatom_comm_destroy(comm)
+          CALL bspatom_problem_destroy(prob)
+          STOP
+        END IF
+        DO rr = 1, world-1
+          o = rr*INT(reclen)
+          r0s = NINT(rbuf(o+1)); nlr = NINT(rbuf(o+2))
+          IF( r0s /= rr*nbase + MIN(rr, nrem) .OR. nlr /= nbase + MERGE(1, 0, rr < nrem) ) THEN
+            WRITE(0,*) 'bsp_atom_host: rank ', rr, ' sent channels ', r0s, nlr, ' (not its block of this run)'
+            STOP 3
+          END IF
+          IF( nlr > 0 ) THEN
+            info(r0s+1:r0s+nlr) = NINT(rbuf(o+4:o+3+nlr))
+            En(r0s*nfun+1:(r0s+nlr)*nfun) = rbuf(o+4+nmax:o+3+nmax+nlr*nfun)
+          END IF
+          IF( rbuf(o+3) == 1.D0 ) THEN
+            ALLOCATE( r(0:npts), u(0:npts) )
+            r(0:npts) = rbuf(o+3+nmax+nmax*nfun+1:o+3+nmax+nmax*nfun+npts+1)
+            u(0:npts) = rbuf(o+3+nmax+nmax*nfun+npts+2:o+3+nmax+nmax*nfun+2*npts+2)
+            have_wf = .TRUE.
+          END IF
+        END DO
+        WRITE(0,'(A,I0,A,I0,A)') 'bsp_atom_host: spectra of ', world, ' rank(s) gathered by RCCL all-gather (',                 &
+     &                           bspatom_comm_collectives(comm), ' collective)'
+        CALL bspatom_comm_destroy(comm)
+        DEALLOCATE( sbuf, rbuf )
+      ELSE IF( world > 1 ) THEN
         IF( rank > 0 ) THEN
 !         written under another name and renamed: rank 0 never sees half a file
-          WRITE(fname,'(A,A,I0)') TRIM(xdir), '/spec.', rank
+          WRITE(fname,'(A,A,A,A,I0)') TRIM(xdir), '/spec.', TRIM(token), '.', rank
           OPEN( UNIT=77, FILE=TRIM(fname)//'.tmp', ACCESS='STREAM', FORM='UNFORMATTED', ACTION='WRITE', STATUS='REPLACE' )
-          WRITE(77) INT(l0s,C_INT32_T), INT(nls,C_INT32_T)
+          WRITE(77) XMAGIC, INT(nfun,C_INT32_T), INT(lmax+1,C_INT32_T), INT(l0s,C_INT32_T), INT(nls,C_INT32_T)
           IF( nls > 0 ) WRITE(77) info(l0s+1:l0s+nls), En(l0s*nfun+1:(l0s+nls)*nfun)
           IF( have_wf ) THEN
             WRITE(77) 1_C_INT32_T, r, u
@@ -380,13 +505,17 @@
             WRITE(77) 0_C_INT32_T
           END IF
           CLOSE(77)
-          CALL EXECUTE_COMMAND_LINE('mv '//TRIM(fname)//'.tmp '//TRIM(fname))
+          rc = c_rename(TRIM(fname)//'.tmp'//C_NULL_CHAR, TRIM(fname)//C_NULL_CHAR)
+          IF( rc /= 0 ) THEN
+            WRITE(0,*) 'bsp_atom_host: cannot rename ', TRIM(fname)
+            STOP 3
+          END IF
           CALL bspatom_problem_destroy(prob)
           STOP
         END IF
-        ALLOCATE( infoall(2) )
+        ALLOCATE( infoall(1) )
         DO rr = 1, world-1                                ! rank 0 collects
-          WRITE(fname,'(A,A,I0)') TRIM(xdir), '/spec.', rr
+          WRITE(fname,'(A,A,A,A,I0)') TRIM(xdir), '/spec.', TRIM(token), '.', rr
           tries = 0
           DO
             INQUIRE( FILE=TRIM(fname), EXIST=ex )
@@ -396,11 +525,17 @@
               WRITE(0,*) 'bsp_atom_host: no spectra from rank ', rr, ' in ', TRIM(xdir)
               STOP 3
             END IF
-            CALL EXECUTE_COMMAND_LINE('sleep 0.05')
+            rc = c_usleep(50000_C_INT)
           END DO
           OPEN( UNIT=77, FILE=TRIM(fname), ACCESS='STREAM', FORM='UNFORMATTED', ACTION='READ', STATUS='OLD' )
-          READ(77) infoall(1), infoall(2)
-          r0s = infoall(1); nlr = infoall(2)
+          READ(77) hdr
+          r0s = hdr(4); nlr = hdr(5)
+!         the file names this run (token) and must describe this problem and exactly rank rr's block of it
+          IF( hdr(1) /= XMAGIC .OR. hdr(2) /= nfun .OR. hdr(3) /= lmax+1 .OR. r0s /= rr*nbase + MIN(rr, nrem) .OR.                  &
+     &        nlr /= nbase + MERGE(1, 0, rr < nrem) ) THEN
+            WRITE(0,*) 'bsp_atom_host: ', TRIM(fname), ' does not belong to this run (header ', hdr, ')'
+            STOP 3
+          END IF
           IF( nlr > 0 ) READ(77) info(r0s+1:r0s+nlr), En(r0s*nfun+1:(r0s+nlr)*nfun)
           READ(77) infoall(1)
           IF( infoall(1) == 1 ) THEN

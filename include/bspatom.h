@@ -136,6 +136,25 @@ int bspatom_last_timing(const bspatom_problem *p, double ms[6]);
 int bspatom_kernel_times(double *ms, int32_t *launches, int cap);
 const char *bspatom_kernel_slot_name(int slot);
 
+/* ---- the one exchange of the sharded path (csrc/comm.hip) ----------------------------------- */
+/* One process per GPU, the l-loop of matrices.f90:242-248 sharded: the ranks exchange nothing while they solve; at the end their
+ * result records are gathered.  These calls give a host without Python (bsp_atom_host.x) the RCCL all-gather that
+ * bspatom_amd/parallel.py issues through torch.distributed.  No reference counterpart (the reference is one process).
+ *   bspatom_run_token   an id shared by the processes of ONE launch and by no other launch: "<pid of the launcher>.<its start
+ *                       time>[.<TORCHELASTIC_RUN_ID>]" (buf: >= 128 bytes).  Also names the files of the no-RCCL fallback.
+ *   bspatom_comm_create collective over `world` processes (rank 0 .. world-1), each on its own GPU (the device of the process's
+ *                       problems).  RCCL is loaded here (dlopen), its unique id travels through `dir`/ncclid.<token>.
+ *                       BSPATOM_ERR_UNSUPPORTED (before anything is exchanged, the same on every rank): more ranks than GPUs
+ *                       (ranks share a device) or no librccl -- the caller falls back to its file exchange.
+ *   bspatom_comm_allgather  recv[r*count .. (r+1)*count) = rank r's send[0 .. count) on every rank (host buffers).
+ *   bspatom_comm_collectives  number of all-gathers issued on this communicator. */
+typedef struct bspatom_comm bspatom_comm;
+int bspatom_run_token(char *buf, int cap);
+int bspatom_comm_create(int rank, int world, const char *dir, bspatom_comm **out);
+int bspatom_comm_allgather(bspatom_comm *c, const double *send, double *recv, long count);
+int bspatom_comm_collectives(const bspatom_comm *c);
+void bspatom_comm_destroy(bspatom_comm *c);
+
 /* ---- LAPACK symbol boundary ---------------------------------------------------- */
 /* Fortran-77 ABI of DSYGV as called at matrices.f90:248.  ITYPE=1, UPLO='U' or 'L'; A and B must
  * be banded with half-width <= 15 (they are, at the reference's call site); JOBZ='N' returns the

@@ -18,6 +18,7 @@ usage: python tests/golden/make_golden.py [case ...]      (default: all small ca
        python tests/golden/make_golden.py --dipole         (KIND_PI = 1, 2 dipole matrices rij)
        python tests/golden/make_golden.py --pi3            (KIND_PI >= 3: state limits, rEki, Eigenvec_All.dat)
        python tests/golden/make_golden.py --amp            (KIND_PI = 1, 2: transition amplitudes T_fi of TRANS_AMP)
+       python tests/golden/make_golden.py --vectors        (eigenvectors of DSYGV('V') at n = 2048: vec_c2_2048.npz)
 """
 import json, os, subprocess, sys, tempfile, time
 import numpy as np
@@ -399,9 +400,48 @@ def run_handoff():
     np.savez_compressed(os.path.join(HERE, "handoff.npz"), **out)
 
 
+def run_vectors(name="c2_2048"):
+    """Eigenvectors of the reference's DSYGV(1,'V','U') call (matrices.f90:248) at n = 2048, channel l = 0, as data: the matrices are
+    the oracle's bands (bit-identical to the reference's Sij and Tij + Uij + Vij, tests/test_oracle_golden.py), the routine is
+    LAPACK 3.12 DSYGV of the library the compiled reference is linked to (scipy's OpenBLAS, oracle/ref/lapack_forward.c) -- the
+    call the reference makes, whose result SOLVE_SYSTEM frees before it returns (matrices.f90:386).  Stored: all eigenvalues; the
+    96 eigenvector columns around the eigenvalue nearest zero (the block's edges moved to the widest gaps nearby), where
+    neighbouring eigenvalues are closest and single vectors are determined worst; 64 columns spread over the spectrum."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as orc
+    from bspatom_amd.namelist import read_namelists
+    nl = read_namelists(open(os.path.join(HERE, "inputs", name + ".inp")).read())
+    c = orc.make_cfg(**{**nl["vars_bsp"], **nl["vars_tise"]})
+    rt, aind, xg, wg = orc.grid(c)
+    SB, HB = orc.assemble_bands(c, rt, aind, xg, wg, 0, 1)
+    t0 = time.time()
+    w, Z, info = orc.dsygv(orc.band_to_dense_upper(HB[0]), orc.band_to_dense_upper(SB), vectors=True)
+    assert info == 0
+    g = np.load(os.path.join(HERE, name + ".npz"))
+    assert np.max(np.abs(w - g["E"][0])) <= 1e-13 * np.max(np.abs(w)), "not the spectrum the reference program wrote"
+    n = len(w)
+    z0 = int(np.argmin(np.abs(w)))
+    gaps = np.diff(w)
+    lo = max(z0 - 48, 8); hi = min(z0 + 48, n - 8)
+    lo = lo - 8 + int(np.argmax(gaps[lo - 8:lo]))  + 1          # block = columns lo .. hi-1, edges at the widest gaps within 8
+    hi = hi + int(np.argmax(gaps[hi - 1:hi + 7])) + 0
+    block = np.arange(lo, hi + 1)
+    sample = np.setdiff1d(np.unique(np.linspace(0, n - 1, 64).astype(int)), block)
+    np.savez_compressed(os.path.join(HERE, "vec_" + name + ".npz"), w=w, block_idx=block, Zblock=Z[:, block], sample_idx=sample,
+                        Zsample=Z[:, sample], gap_below=np.array(gaps[lo - 1]), gap_above=np.array(gaps[hi]),
+                        source=np.array("scipy.linalg.lapack.dsygv (OpenBLAS 0.3.28 / LAPACK 3.12.0) on the oracle's bit-exact bands; "
+                                        "%.0f s" % (time.time() - t0)))
+    print("vec_%s: n = %d, block %d..%d (gaps at its edges %.2e / %.2e, smallest inside %.2e), %d sample columns"
+          % (name, n, lo, hi, gaps[lo - 1], gaps[hi], gaps[lo:hi].min(), len(sample)))
+
+
 def main():
     if "--handoff" in sys.argv[1:]:
         run_handoff()
+        return
+    if "--vectors" in sys.argv[1:]:
+        run_vectors()
         return
     if not os.path.exists(REFX):
         sys.exit("oracle/_ref/ref_dump.x missing: run oracle/ref/build_ref.sh first")

@@ -14,12 +14,12 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_bench_under_torchrun_one_rank(scaling):
-    port = 29600 + os.getpid() % 300 + (0 if scaling == "weak" else 1)
+@pytest.mark.parametrize("scaling,route", [("weak", 0), ("strong", 0), ("weak", 1)])
+def test_bench_under_torchrun_one_rank(scaling, route):
+    port = 29600 + os.getpid() % 300 + (0 if scaling == "weak" else 1) + 2 * route
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
-           "--nfun", "1024", "--rb", "200", "--channels", "8", "--scaling", scaling, "--no-cpu-baseline"]
+           "--nfun", "1024", "--rb", "200", "--channels", "8", "--scaling", scaling, "--no-cpu-baseline", "--route", str(route)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
@@ -37,12 +37,20 @@ def test_bench_under_torchrun_one_rank(scaling):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     # per-kernel entries: launch durations measured in this run (HIP events around every launch), frac = work / time
     ks = {k["kernel"].split("(")[0].split("<")[0].strip(): k for k in r["kernels"]}
-    for name in ("gemm2_kernel", "sb2sb_mfma_kernel", "sb16r_kernel / sb16st_kernel"):
+    # default route at k = 9: the band route (csrc/crawford.hip); --route 1: the dense route, whose line lists the two big GEMMs
+    assert d["route"] == ("dense" if route == 1 else "band")
+    want = ("gemm2_kernel",) if route == 1 else ("crawford_item_kernel", "sb16r_kernel / sb16st_kernel", "bisect3_kernel")
+    for name in want:
         assert name in ks, list(ks)
     for k in r["kernels"]:
         if "launches_per_step" in k:
             assert k["launches_per_step"] > 0 and k["kernel_ms_per_step"] > 0 and "this run" in k["launch_ms_source"]
             assert 0 < k["frac"] < 1 and abs(k["frac"] - k["achieved"] / k["peak"]) < 1e-9
+    if route == 0:
+        # the two extra legs of a one-GPU run: north_star's dense route and the all-eigenvectors call, measured in the same run
+        assert d["dense_two_stage"]["value"] > 0 and 0 < d["dense_two_stage"]["roofline"]["frac"] < 1
+        assert d["full_V"]["unit"] == "channels/s" and d["full_V"]["check_64_vectors"]["max_S_orthonormality_defect"] < 1e-11
+        assert d["roofline"]["dense_algorithm_ceiling"]["eigensolves_per_s_at_100_percent_of_fp64_peak"] > 0
 
 
 def test_sharded_host_under_torchrun(tmp_path):

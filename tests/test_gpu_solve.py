@@ -274,7 +274,9 @@ def test_fortran_host_sharded(tmp_path, world, l_ini):
     """bsp_atom_host.x as one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE in the environment, as a launcher sets them): every
     rank solves its block of l-channels (the loop of matrices.f90:242-248, sharded), the spectra and the consumed eigenvector's
     table reach rank 0 through the files of BSPATOM_XCHG, and rank 0's stdout, Enl.dat and wf_n0.dat are byte for byte what the
-    single process writes -- also when another rank owns l_ini.  The test box has one GPU: every rank is sent to device 0."""
+    single process writes -- also when another rank owns l_ini.  The test box has one GPU: every rank is sent to device 0, so
+    bspatom_comm_create answers UNSUPPORTED (more ranks than GPUs) on every rank and the host takes its file exchange -- the
+    fallback of the RCCL all-gather that ranks on GPUs of their own use (test_fortran_host_rccl_gather_world1)."""
     import subprocess
     exe = os.path.join(ROOT, "bspatom_amd", "bsp_atom_host.x")
     if not os.path.exists(exe):
@@ -287,6 +289,11 @@ def test_fortran_host_sharded(tmp_path, world, l_ini):
         p1 = subprocess.run([exe], stdin=fin, cwd=one, capture_output=True, text=True, timeout=300)
     assert p1.returncode == 0 and "Program Finished!" in p1.stdout, p1.stdout + p1.stderr
     many = tmp_path / "many"; many.mkdir()
+    # what an earlier run may have left in the exchange directory (round-3 advisor finding: rank 0 took any spec.<r> it found for
+    # this run's): a file of the old naming and one of another launch, both with rank 1's name and garbage inside
+    (tmp_path / "xchg").mkdir()
+    (tmp_path / "xchg" / "spec.1").write_bytes(b"\x00" * 4096)
+    (tmp_path / "xchg" / "spec.12345.678.1").write_bytes(b"\x07" * 4096)
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), BSPATOM_DEVICE="0",
@@ -301,7 +308,8 @@ def test_fortran_host_sharded(tmp_path, world, l_ini):
     assert outs[0][0] == p1.stdout
     assert open(many / "Enl.dat").read() == open(one / "Enl.dat").read()
     assert open(many / "wf_n0.dat").read() == open(one / "wf_n0.dat").read()
-    assert not list((tmp_path / "xchg").glob("spec.*"))    # consumed
+    left = sorted(f.name for f in (tmp_path / "xchg").iterdir())
+    assert left == ["spec.1", "spec.12345.678.1"], left    # this run's files consumed, the stale ones never touched
 
 
 @pytest.mark.gpu
@@ -327,6 +335,40 @@ def test_fortran_host_under_torchrun(tmp_path):
     assert open(many / "Enl.dat").read() == open(one / "Enl.dat").read()
     assert open(many / "wf_n0.dat").read() == open(one / "wf_n0.dat").read()
     assert p1.stdout in p.stdout                            # the launcher may add lines of its own around rank 0's
+
+
+@pytest.mark.gpu
+def test_fortran_host_rccl_gather_world1(tmp_path):
+    """north_star's letter below Python: bsp_atom_host.x gathers the spectra with an RCCL all-gather issued by libbspatom itself
+    (csrc/comm.hip: bspatom_comm_create / _allgather), no torch in the process.  One rank under the launcher is all a one-GPU box
+    can connect: the host still creates the communicator (ncclCommInitRank), sends its record through ncclAllGather and unpacks
+    it -- stderr says so -- and writes byte for byte the single process's outputs."""
+    import subprocess, sys
+    exe = os.path.join(ROOT, "bspatom_amd", "bsp_atom_host.x")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran host not built (no flang)")
+    inp = golden_input("simfues")
+    one = tmp_path / "one"; one.mkdir()
+    with open(inp) as fin:
+        p1 = subprocess.run([exe], stdin=fin, cwd=one, capture_output=True, text=True, timeout=300)
+    assert p1.returncode == 0, p1.stdout + p1.stderr
+    assert "RCCL" not in p1.stderr                          # no launcher, no communicator
+    many = tmp_path / "many"; many.mkdir()
+    env = dict(os.environ, BSPATOM_INPUT=os.path.abspath(inp), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("BSPATOM_XCHG", None); env.pop("BSPATOM_XCHG_MODE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--no-python", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(29860 + os.getpid() % 30), exe]
+    p = subprocess.run(cmd, cwd=many, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "spectra of 1 rank(s) gathered by RCCL all-gather (1 collective)" in p.stderr, p.stderr[-2000:]
+    assert open(many / "Enl.dat").read() == open(one / "Enl.dat").read()
+    assert open(many / "wf_n0.dat").read() == open(one / "wf_n0.dat").read()
+    assert p1.stdout in p.stdout
+    # the same launch with the file exchange forced: no communicator
+    files = tmp_path / "files"; files.mkdir()
+    p = subprocess.run(cmd, cwd=files, env=dict(env, BSPATOM_XCHG_MODE="files"), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "RCCL" not in p.stderr, p.stderr[-2000:]
+    assert open(files / "Enl.dat").read() == open(one / "Enl.dat").read()
 
 
 def test_python_host_outputs(tmp_path):
@@ -880,17 +922,30 @@ def test_bsp_dsygv_all_vectors_at_2048():
     orth = np.max(np.abs(Z.T @ SZ - np.eye(c.nfun)))
     resid = np.max(np.abs(Hf @ Z - SZ * w)) / np.max(np.abs(w))
     note("bsp_dsygv_('V') n=2048: Z^T S Z - I %.2e  residual/lambda_max %.2e" % (orth, resid))
-    assert orth <= 1e-8 and resid <= 1e-11
+    assert orth <= 1e-12 and resid <= 1e-11                 # LAPACK's DSYGV delivers ~n eps on the same pencil (round-3 verdict: 1e-8 was loose)
     assert np.max(np.abs(np.triu(U).T @ np.triu(U) - Sf)) < 1e-12
+    # against the vectors LAPACK's DSYGV('V') returns for this pencil (tests/golden/vec_c2_2048.npz, make_golden.py --vectors):
+    # the invariant subspace of the 72 eigenvalues around zero, where single vectors are determined worst (smallest gap 4.6e-4),
+    # and 62 isolated vectors spread over the spectrum up to sign
+    v = load_golden("vec_c2_2048")
+    blk, smp = v["block_idx"], v["sample_idx"]
+    assert np.max(np.abs(w - v["w"])) <= 1e-13 * np.max(np.abs(w))
+    sv = np.linalg.svd(v["Zblock"].T @ SZ[:, blk], compute_uv=False)
+    dots = np.sum(v["Zsample"] * SZ[:, smp], axis=0)        # z_ref^T S z_gpu = +-1
+    diff = np.max(np.abs(Z[:, smp] * np.sign(dots) - v["Zsample"]), axis=0)
+    note("bsp_dsygv_('V') n=2048 vs LAPACK's vectors: block of %d around zero: singular values of Zref^T S Zgpu in [%.3e below 1, %.3e above]; "
+         "%d isolated vectors: max |z_gpu -+ z_ref| %.2e" % (len(blk), 1 - sv.min(), sv.max() - 1, len(smp), diff.max()))
+    assert np.max(np.abs(sv - 1.0)) <= 1e-10
+    assert diff.max() <= 1e-9
 
 
 def test_bsp_dsygv_all_vectors_at_4096_timed():
     """The full DSYGV(1,'V','U') contract at the size of BASELINE configs[3] (matrices.f90:248; n = 4096, the reference's
     SOLVE_SYSTEM takes 44 s per channel for it on 16 host cores): all 4096 S-orthonormal eigenvectors through the LAPACK-symbol
     boundary, TIMED (wall time of the call, host buffers in and out: two dense 134 MB matrices; noted in
-    gpurun_out/stage_metrics.txt and copied to profiles/).  The eigenvalue clusters of this pencil (neighbours closer than
-    1e-5 lambda_max, chained) reach 1001 members: round 2's host-side Gram-Schmidt was O(m^2 n k) there (advisor finding); the
-    blocked S-orthonormalisation now runs on the GPU (csrc/dsygv.hip)."""
+    gpurun_out/stage_metrics.txt and copied to profiles/).  Round 4: the clusters are LAPACK DSTEIN's (neighbours closer than
+    1e-3 lambda_max, chained; round 3 used 1e-5 and left 7e-11 of S-orthonormality defect between vectors just outside a cluster) --
+    on this pencil that is the whole spectrum; the blocked S-orthonormalisation runs on the GPU (csrc/dsygv.hip)."""
     import time
     import oracle as orc
     from tests_truth import case_cfg
@@ -916,12 +971,12 @@ def test_bsp_dsygv_all_vectors_at_4096_timed():
     SZ = Sf @ Z
     orth = np.max(np.abs(Z.T @ SZ - np.eye(c.nfun)))
     resid = np.max(np.abs(Hf @ Z - SZ * w)) / np.max(np.abs(w))
-    lam = np.max(np.abs(w)); gaps = np.diff(w) <= 1e-5 * lam
+    lam = np.max(np.abs(w)); gaps = np.diff(w) <= 1e-3 * lam
     runs = np.diff(np.flatnonzero(np.diff(np.concatenate([[0], gaps.astype(int), [0]]))))[::2] + 1 if gaps.any() else np.array([1])
     note("bsp_dsygv_ n=4096 one channel through the dsygv_ symbol boundary (host matrices in, host results out; ctypes wrapper incl. its "
          "two contiguous 134 MB copies): JOBZ='N' first call %.2f s, repeated %.2f s, JOBZ='V' (all 4096 vectors) %.2f s; largest "
          "eigenvalue cluster %d; Z^T S Z - I %.2e  residual/lambda_max %.2e" % (tN1, tN, tV, int(runs.max()), orth, resid))
-    assert orth <= 1e-8 and resid <= 1e-11
+    assert orth <= 1e-12 and resid <= 1e-11
     assert tV < 30.0          # the reference's DSYGV('V') on 16 host cores: 44 s (bench.py cpu_baseline, same box)
 
 

@@ -565,3 +565,60 @@ def test_two_step_band_reduction_prototype():
             m.sb2sb(np.array(A16 + 0.0) * 0 + np.triu(np.tril(rng.standard_normal((n, n)), m.B), -m.B))
     finally:
         m.LAG = 3
+
+
+def test_no_scratch_in_the_kernels_of_the_default_route():
+    """Round-3 verdict, item 6: the code-object notes of libbspatom.so (llvm-readelf --notes through tools/codeobj_notes.py) -- a
+    kernel that the default route of a BASELINE config launches must not use scratch (private_segment_fixed_size = 0).  The band
+    route (configs 1-4: assembly, crawford.hip, the band-16 chase, bisection, the consumed eigenvector, WRITE_WF) has none.  The
+    dense route (config 5, k = 11) still has the listed, capped exceptions; nothing else in the library may spill, and the
+    listed ones may not grow."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import codeobj_notes
+    ks = codeobj_notes.kernels(os.path.join(ROOT, "bspatom_amd", "libbspatom.so"))
+    assert len(ks) > 60
+    # kernel (substring of the demangled name) -> bytes of scratch it may have at most, and why it is tolerated
+    allowed = {
+        "tsqr_tree_kernel<2>": 176,     # dense route, panels <= 2048 rows: 43 registers spilled; scratch stores before the level loop,
+        "tsqr_apply_kernel<2>": 208,    # one dword reloaded per column step (DESIGN 4.2a); the uncapped <1> instances have none
+        "panel_qr_kernel<16>": 508,     # dense route, panels of 4097 .. 8192 rows (n > 4160 only: config 5)
+        "panel_qr_kernel<8>": 76,       # BSP_PANEL_QR=1 cross-check
+        "panel_qr2_kernel<16>": 436,    # instantiated, never launched (launch_pq: RPT <= 8)
+        "sb2st_kernel_v7<1>": 40,       # the instrumented instance of BSP_SB2ST_DIAG
+    }
+    band_route = ["point_table_kernel", "band_kernel", "crawford_item_kernel", "crawford_setup_kernel", "crawford_init_kernel",
+                  "crawford_band_kernel", "crawford_flip_kernel", "band_cholesky_kernel", "sb16r_kernel", "band_tail_zero_kernel",
+                  "bisect3_kernel", "bisect_one3_kernel", "invit_kernel", "wf_kernel"]
+    seen = {b: 0 for b in band_route}
+    bad = []
+    for name, v in ks.items():
+        cap = next((c for a, c in allowed.items() if a in name), 0)
+        if (v["private_segment_fixed_size"] or 0) > cap:
+            bad.append((name, v["private_segment_fixed_size"], cap))
+        for b in band_route:
+            if b in name:
+                seen[b] += 1
+                assert not v["private_segment_fixed_size"] and not v["vgpr_spill_count"], (name, v)
+    assert not bad, bad
+    assert all(seen.values()), seen
+
+
+def test_accuracy_ratchet_file_only_tightens():
+    """tests/golden/accuracy_ratchet.json (round-3 verdict, item 4): every case carries `best` for the gated figures, no `best` is
+    looser than the three files of round 3 it was seeded from, and an override names its route, its bar and a reason."""
+    import json
+    from tests_truth import GATED
+    doc = json.load(open(os.path.join(ROOT, "tests", "golden", "accuracy_ratchet.json")))
+    seed = {"c4_4096_l127": (0.08173091737950636, 33), "sf2048": (0.019458441628511368, 3), "c3_2048_l31": (0.08051401133617608, 9),
+            "c3_1024_l31": (0.0741926373941524, 3), "c2_2048": (0.08051401133617608, 0), "c5_8192": (0.057375, 2)}
+    assert len(doc["cases"]) >= 22
+    for name, e in doc["cases"].items():
+        assert set(GATED) <= set(e["best"]), name
+        if name in seed:
+            assert e["best"]["near_zero"] <= seed[name][0] * (1 + 1e-12) + (1e-3 if name == "c5_8192" else 0), (name, e["best"])
+            assert e["best"]["n_beyond"] <= seed[name][1], (name, e["best"])
+        for route, figs in e.get("override", {}).items():
+            assert route in ("route1", "route2"), (name, route)
+            for fig, o in figs.items():
+                assert fig in GATED and o["bar"] >= o["measured"] and len(o["why"]) > 40, (name, route, fig)

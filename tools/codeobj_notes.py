@@ -46,9 +46,12 @@ def kernels(lib):
                     cur[f.lstrip(".")] = int(m.group(1)) if m else None
                 out[name.group(1)] = cur
     names = list(out)
-    dem = subprocess.run([os.path.join(LLVM, "llvm-cxxfilt")] + names, capture_output=True, text=True).stdout.split("\n") \
-        if os.path.exists(os.path.join(LLVM, "llvm-cxxfilt")) else names
-    return {(dem[i] if i < len(dem) and dem[i] else n): out[n] for i, n in enumerate(names)}
+    import shutil
+    filt = shutil.which("c++filt") or (os.path.join(LLVM, "llvm-cxxfilt") if os.path.exists(os.path.join(LLVM, "llvm-cxxfilt")) else None)
+    dem = subprocess.run([filt] + names, capture_output=True, text=True).stdout.split("\n") if filt else names
+    # "void bsp::(anonymous namespace)::tsqr_tree_kernel<2>(bsp::(anonymous namespace)::TsqrArgs)" -> "bsp::tsqr_tree_kernel<2>"
+    short = lambda d: d.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    return {(short(dem[i]) if i < len(dem) and dem[i] else n): out[n] for i, n in enumerate(names)}
 
 
 if __name__ == "__main__":
