@@ -614,10 +614,13 @@ def test_accuracy_ratchet_file_only_tightens():
             "c3_1024_l31": (0.0741926373941524, 3), "c2_2048": (0.08051401133617608, 0), "c5_8192": (0.057375, 2)}
     assert len(doc["cases"]) >= 22
     for name, e in doc["cases"].items():
-        assert set(GATED) <= set(e["best"]), name
-        if name in seed:
-            assert e["best"]["near_zero"] <= seed[name][0] * (1 + 1e-12) + (1e-3 if name == "c5_8192" else 0), (name, e["best"])
-            assert e["best"]["n_beyond"] <= seed[name][1], (name, e["best"])
+        assert e["default_route"] in (1, 2) and "route%d" % e["default_route"] in e["best"], name
+        for b in e["best"].values():
+            assert set(GATED) <= set(b), name
+        if name in seed:                                                        # the dense route's history
+            b = e["best"]["route1"]
+            assert b["near_zero"] <= seed[name][0] * (1 + 1e-12) + (1e-3 if name == "c5_8192" else 0), (name, b)
+            assert b["n_beyond"] <= seed[name][1], (name, b)
         for route, figs in e.get("override", {}).items():
             assert route in ("route1", "route2"), (name, route)
             for fig, o in figs.items():

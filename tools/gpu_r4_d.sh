@@ -2,7 +2,7 @@
 # round 4: the whole -m gpu suite, smoke, the default bench line (with the dense and full-V legs)
 set -o pipefail
 O=gpurun_out/r4d; mkdir -p $O; rm -f gpurun_out/stage_metrics.txt
-timeout -k 10 1000 python -m pytest tests -m gpu -q -p no:cacheprovider -x > $O/pytest.log 2>&1; rc=$?
+timeout -k 10 1000 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest.log 2>&1; rc=$?
 echo "pytest exit $rc"; tail -12 $O/pytest.log | cut -c1-300
 [ $rc -ge 124 ] && exit $rc
 timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || { tail -5 $O/smoke.log; }

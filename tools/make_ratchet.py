@@ -39,23 +39,25 @@ def csrc_sha():
 
 
 def merge(entry, a, sha, allow, name, route):
-    """fold the measurement `a` into the committed entry; returns the violated gates that were not allowed"""
+    """fold the measurement `a` of `route` into the committed entry; returns the violated gates that were not allowed"""
     linear = entry.get("kind_grid", 0) == 0
-    bad = [] if not entry.get("best") else ratchet_violations(entry, a, linear, route)
-    best = dict(entry.get("best") or {})
+    key = "route%d" % route
+    bad = ratchet_violations(entry, a, linear, route) if entry.get("best") else []
+    best = dict(entry.setdefault("best", {}).get(key) or {})
     for fig in GATED:
         old = best.get(fig)
         best[fig] = a[fig] if old is None else min(old, a[fig])
-    entry["best"] = best
+    entry["best"][key] = best
     last = {k: a[k] for k in ("worst_rel", "max_abs", "near_zero", "n_beyond")}
     last["csrc_sha16"] = sha
-    entry.setdefault("last", {})["route%d" % route] = last     # per route: 1 dense, 2 band
+    entry.setdefault("last", {})[key] = last
     left = []
     for fig, val, bar in bad:
         why = allow.get((name, fig))
         if why:
-            entry.setdefault("override", {}).setdefault("route%d" % route, {})[fig] = {"bar": (max(int(2 * val), val + 2) if fig == "n_beyond" else 2.0 * val),
-                                                     "measured": val, "gate_without_override": bar, "why": why, "csrc_sha16": sha}
+            entry.setdefault("override", {}).setdefault(key, {})[fig] = {
+                "bar": (max(int(2 * val), val + 2) if fig == "n_beyond" else 2.0 * val), "measured": val, "gate_without_override": bar,
+                "why": why, "csrc_sha16": sha}
         else:
             left.append((fig, val, bar))
     return left
@@ -96,9 +98,12 @@ def main():
         nch = max(chans) + 1
         prob = capi.Problem(inp_of(name))
         route = prob.route()                               # 1 dense, 2 band: what this case takes under the current switch
+        capi.set_option("route", 0)
+        default_route = prob.route()
+        capi.set_option("route", args.route or 0)
         E, info = prob.solve(0, nch)
         assert np.all(info == 0)
-        per, where = [], None
+        per, where, where_abs = [], None, None
         for l in chans:
             sel = t["chan"] == l
             per.append(truth_stats(E[l], Eref[l], t["idx"][sel], t["hi"][sel]))
@@ -107,14 +112,19 @@ def main():
             near = np.argsort(np.abs(tru))[:24]
             eg = np.abs(E[l][idx] - tru)[near]
             q = int(np.argmax(eg))
+            ea = np.abs(E[l][idx] - tru); qa = int(np.argmax(ea))
+            if where_abs is None or per[-1]["max_abs"] >= where_abs[0]:
+                where_abs = (per[-1]["max_abs"], "l = %d, eigenvalue %d, E = %.6e: |E_gpu - truth| = %.2e, |E_ref - truth| = %.2e"
+                             % (l, int(idx[qa]) + 1, tru[qa], ea[qa], abs(Eref[l][idx[qa]] - tru[qa])))
             if where is None or per[-1]["near_zero"] >= where[0]:
                 where = (per[-1]["near_zero"], "l = %d, eigenvalue %d, E = %.6e: |E_gpu - truth| = %.2e, |E_ref - truth| = %.2e, lambda_max = %.3e"
                          % (l, int(idx[near][q]) + 1, tru[near][q], eg[q], abs(Eref[l][idx[near][q]] - tru[near][q]), float(np.max(np.abs(Eref[l])))))
         a = aggregate_stats(per)
         entry = doc["cases"].setdefault(name, {})
-        entry.update({"channels": a["channels"], "n_truth": a["n_truth"], "kind_grid": int(inp_of(name).kind_grid), "nfun": int(prob.nfun)})
+        entry.update({"channels": a["channels"], "n_truth": a["n_truth"], "kind_grid": int(inp_of(name).kind_grid), "nfun": int(prob.nfun),
+                      "default_route": default_route})
         left = merge(entry, a, sha, allow, name, route)
-        print(name, "route", route, {k: a[k] for k in ("max_abs", "near_zero", "n_beyond", "worst_rel")}, "best", entry["best"], "| near zero:", where[1],
+        print(name, "route", route, {k: a[k] for k in ("max_abs", "near_zero", "n_beyond", "worst_rel")}, "best", entry["best"]["route%d" % route], "| near zero:", where[1], "| max abs:", where_abs[1],
               ("OVER THE GATE: " + ", ".join("%s %.4g > %.4g" % v for v in left)) if left else "", flush=True)
         failed += [(name,) + v for v in left]
         prob.close()
