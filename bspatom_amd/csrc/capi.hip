@@ -79,6 +79,7 @@ const OptName OPT_TABLE[] = {
     {"ktime", "BSP_KTIME", &Options::ktime}, {"tsqr_regcap", "BSP_TSQR_REGCAP", &Options::tsqr_regcap},
     {"tsqr_max_m", "BSP_TSQR_MAX_M", &Options::tsqr_max_m}, {"sb16_rows", "BSP_SB16_ROWS", &Options::sb16_rows},
     {"route", "BSP_ROUTE", &Options::route}, {"cw_onediv", "BSP_CW_ONEDIV", &Options::cw_onediv},
+    {"fused_probe", "BSP_FUSED_PROBE", &Options::fused_probe},
 };
 }  // namespace
 

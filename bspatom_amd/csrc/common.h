@@ -62,6 +62,8 @@ struct Options {
     int route = 0;               // BSP_ROUTE: 0 = by size (the band route wherever crawford_supported), 1 = dense route (standard form, sy2sb,
                                  // two-step bulge chasing: north_star's letter, and every pencil wider than 8), 2 = band route (crawford.hip:
                                  // the pencil stays banded; band-16 chase; UNSUPPORTED where it cannot run)
+    int fused_probe = 0;         // BSP_FUSED_PROBE: TIMING EXPERIMENT ONLY (wrong results): the rank-128 update runs 16 K-steps instead of 8 and
+                                 // symm is not launched -- the upper bound of what a fused update + symm sweep over A22 can gain (round-3 verdict, item 1)
     int cw_onediv = 0;           // BSP_CW_ONEDIV: reflectors of the band route's RQ loop in the one-division form (A/B switch)
     int ktime = 0;               // 1: HIP events around every launch of the kernels in KSlot (bspatom_kernel_times; bench.py's
                                  // per-kernel roofline entries are measured with it in one extra, untimed step)

@@ -644,7 +644,7 @@ int syr2k_lower_f64(int m, int batch, double *A22, long ld, long bsA, const doub
                     int part, hipStream_t st)
 {
     GemmDesc g{};
-    g.M = m; g.N = m; g.K = 128; g.batch = batch;
+    g.M = m; g.N = m; g.K = opts().fused_probe ? 256 : 128; g.batch = batch;   // probe: reads 128 columns past [V|Z|V] (its neighbours in the work area)
     g.A = buf + 64 * ldb; g.sAm = 1; g.sAk = ldb; g.bA = bsBuf;      // kernel-A(i'=c, k) = Q(c, k)
     g.B = buf; g.sBn = 1; g.sBk = ldb; g.bB = bsBuf;                  // kernel-B(k, j'=r) = P(r, k)
     g.C = A22; g.sCm = ld; g.sCn = 1; g.bC = bsA;                     // C'(c, r) = A22(r, c)

@@ -674,7 +674,8 @@ static int sy2sb_panel(int npad, int batch, double *d_A, const Sy2sbWork &w, hip
         GemmDesc g{};
         g.batch = batch;
         // Y = A22 W  -> buf[:, NB:2NB]   (A22 valid on 64-blocks J <= I+1 only)
-        if ((rc = symm_lower_f64(m, batch, A22, ld, bsA, w.W, npad, bsW, buf + (size_t)NB * npad, npad, bsBuf, st))) return rc;
+        if (!opts().fused_probe &&
+            (rc = symm_lower_f64(m, batch, A22, ld, bsA, w.W, npad, bsW, buf + (size_t)NB * npad, npad, bsBuf, st))) return rc;
         // K = W^T Y
         {
             KScope kt(KS_CHAIN, st);
