@@ -237,6 +237,238 @@ __global__ __launch_bounds__(256) void crawford_item_kernel(int N, int t, int jl
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// crawford_item4_kernel: FOUR chase items per wave.  The kernel above spends a third of its ~1400 vector instructions per item
+// on the DPP moves of 16-lane row sums (every dot product of the RQ loop is a reduction ACROSS lanes).  Here the layout is
+// turned round for the RQ loop, as in the band-16 chase (sbr2.hip: "a chase item per row of 16 lanes"): a DPP row of 16 lanes
+// owns an item, lane r of it holds ROW r of Q (16 doubles) and, for r < 8, row r of X = [F E] -- the reflector u is the same in
+// all 16 lanes (row I of X goes round through 128 bytes of LDS: written by its lane, read back by the row as a broadcast), so
+// every dot product is a sum INSIDE a lane: 16 FMAs for four items at once instead of 12 instructions of rotation-and-add for
+// four rows of one item.  ~40 instructions per item and reflector instead of ~170.  The Q of each item then goes through LDS
+// into the accumulator layout of the matrix cores (2 KB per item) and the congruences run exactly as above, one item at a time.
+// The arithmetic of an item is the first kernel's in another summation order (sums over 16 columns run 0 .. 15 inside a lane
+// instead of as a butterfly): spectra agree to rounding, not bit for bit; BSP_CW_ITEMS4=0 keeps the first kernel as the cross-check.
+constexpr int QLD = 18;                                                  // LDS row stride of a stored Q (doubles): 144 B, 16-byte aligned
+
+template <int I, bool ONEDIV>
+__device__ __forceinline__ void rq4_step(double (&x)[16], double (&q)[16], double *bc, const int r)
+{
+    constexpr int LEN = CB + I;
+    // row I of X to every lane of the DPP row (bc: this item's 16 doubles of LDS; one wave, LDS operations complete in order)
+    if (r == I) {
+#pragma unroll
+        for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2 *>(bc + c) = make_double2(x[c], x[c + 1]);
+    }
+    // The reads below are OTHER lanes' reads of lane I's stores: a data race in the language's per-thread view, so without
+    // this barrier the compiler moves the reads of the lanes r != I in front of the store and forwards lane I its own
+    // registers (it did: wrong results that changed from run to run).  The hardware needs nothing: one wave's LDS
+    // operations complete in order.
+    asm volatile("" ::: "memory");
+    double u[16];
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) {
+        if (c <= LEN) {
+            const double2 v = *reinterpret_cast<const double2 *>(bc + c);
+            u[c] = v.x; u[c + 1] = v.y;
+        }
+    }
+    asm volatile("" ::: "memory");                                      // the next step's store stays behind these reads
+    double sg[4] = {0.0, 0.0, 0.0, 0.0};                                // four partial sums: a chain of 16 dependent FMAs is all latency
+#pragma unroll
+    for (int c = 0; c < LEN; ++c) sg[c & 3] = fma(u[c], u[c], sg[c & 3]);
+    const double sig = (sg[0] + sg[1]) + (sg[2] + sg[3]);
+    const double alpha = u[LEN];
+    const double a2s = fma(alpha, alpha, sig);
+    const bool ok = (a2s > 1e-280) && (sig != 0.0);                    // nothing (numerically) left of the pivot: H = I
+    const double nrm = sqrt(ok ? a2s : 1.0);
+    const double bt = (alpha >= 0.0) ? -nrm : nrm;
+    const double amb = alpha - bt;
+    const double sc = ONEDIV ? 1.0 : (ok ? 1.0 / amb : 0.0);
+    const double t = ok ? (ONEDIV ? -1.0 / (bt * amb) : (bt - alpha) / bt) : 0.0;
+    const double beta = ok ? bt : alpha;
+    if (!ONEDIV) {
+#pragma unroll
+        for (int c = 0; c < LEN; ++c) u[c] *= sc;
+    }
+    u[LEN] = ONEDIV ? amb : 1.0;
+    {   // rows up to and INCLUDING I (lanes r <= I); the others keep their x.  Row I goes through the same update as the rows
+        // above it: it comes out as (rounding residue .. , beta, *) instead of exact zeros.  Nothing needs them exact: the F part of
+        // X is never stored (it IS the annihilated fill), the part of row I left of the pivot inside E_{p+1} is below the diagonal
+        // of an 8 x 8 block that is full in this band form anyway, and no later reflector touches a row below its own.  (Writing
+        // the zeros was 32 conditional moves per reflector, a tenth of the kernel's instructions.)
+        double ws[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c <= LEN; ++c) ws[c & 3] = fma(x[c], u[c], ws[c & 3]);
+        const double w = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+        const double tw = (r <= I) ? -t * w : 0.0;
+#pragma unroll
+        for (int c = 0; c <= LEN; ++c) x[c] = fma(tw, u[c], x[c]);
+    }
+    (void)beta;
+    {
+        double ws[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c <= LEN; ++c) ws[c & 3] = fma(q[c], u[c], ws[c & 3]);
+        const double w = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+        const double tw = -t * w;
+#pragma unroll
+        for (int c = 0; c <= LEN; ++c) q[c] = fma(tw, u[c], q[c]);
+    }
+}
+
+template <bool ONEDIV, int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, int t, int jlo, int nch, int jel,
+                                                            const double *__restrict__ Qel, double *Dall, double *Eall, double *Gall)
+{
+    __shared__ __attribute__((aligned(16))) double Qs[NW][4][16 * QLD];  // per wave and item slot: Q, row-major, stride QLD
+    __shared__ __attribute__((aligned(16))) double Bc[NW][4][16];        // per wave and item slot: the row that goes round
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int idx0 = (blockIdx.x * NW + wave) * 4;                       // first of this wave's four items
+    const int items = nch + (jel > 0 ? 1 : 0);
+    if (idx0 >= items) return;
+    const size_t chn = (size_t)blockIdx.y * N * CBB;
+    double *D = Dall + chn, *E = Eall + chn, *G = Gall + chn;
+
+    // ---- phase A: the RQ loops of the wave's chase items, an item per DPP row ----
+    if (idx0 < nch) {
+        const int it = lane >> 4, r = lane & 15;
+        const int idx = idx0 + it;
+        const bool live = idx < nch && r < CB;                           // lanes that hold a row of X
+        const int j = jlo + (idx < nch ? idx : 0), p = j - 2 - (t - 2 * j);
+        double x[16], q[16];
+        {
+            const double *gp = G + (size_t)p * CBB + (r & 7) * CB, *ep = E + (size_t)(p + 1) * CBB + (r & 7) * CB;
+#pragma unroll
+            for (int c = 0; c < CB; c += 2) {
+                const double2 a = *reinterpret_cast<const double2 *>(gp + c), b = *reinterpret_cast<const double2 *>(ep + c);
+                x[c] = live ? a.x : 0.0; x[c + 1] = live ? a.y : 0.0;
+                x[CB + c] = live ? b.x : 0.0; x[CB + c + 1] = live ? b.y : 0.0;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) q[c] = (c == r) ? 1.0 : 0.0;
+        double *bc = &Bc[wave][it][0];
+        rq4_step<7, ONEDIV>(x, q, bc, r);
+        rq4_step<6, ONEDIV>(x, q, bc, r);
+        rq4_step<5, ONEDIV>(x, q, bc, r);
+        rq4_step<4, ONEDIV>(x, q, bc, r);
+        rq4_step<3, ONEDIV>(x, q, bc, r);
+        rq4_step<2, ONEDIV>(x, q, bc, r);
+        rq4_step<1, ONEDIV>(x, q, bc, r);
+        rq4_step<0, ONEDIV>(x, q, bc, r);
+        if (live) {                                                      // E_{p+1} <- R
+            double *ep = E + (size_t)(p + 1) * CBB + r * CB;
+#pragma unroll
+            for (int c = 0; c < CB; c += 2) *reinterpret_cast<double2 *>(ep + c) = make_double2(x[CB + c], x[CB + c + 1]);
+        }
+        double *qs = &Qs[wave][it][r * QLD];
+#pragma unroll
+        for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2 *>(qs + c) = make_double2(q[c], q[c + 1]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this wave's own LDS stores (no other wave reads them)
+
+    // ---- phase B: the congruences, one item at a time, in the layout of the matrix cores.  The operands of all four items are
+    // requested before the first product (a slot without an item reads slot 0's addresses and is skipped): one round trip to
+    // memory per wave instead of one per item. ----
+    const int g = lane >> 4, c = lane & 15, c8 = c & 7;
+    const bool left = c < CB;
+    int kind[4], jj[4], pp[4];                                           // kind: 0 none, 1 chase, 2 elimination
+    double wv[4][4], sdv[4][2], qe[4], xt[2] = {0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int idx = idx0 + s;
+        kind[s] = idx < nch ? 1 : ((idx == nch && jel > 0) ? 2 : 0);
+        jj[s] = kind[s] == 1 ? jlo + idx : (kind[s] == 2 ? jel : jlo + idx0);
+        pp[s] = kind[s] == 2 ? jel - 1 : jj[s] - 2 - (t - 2 * jj[s]);
+        if (kind[s] == 0) { jj[s] = jj[0]; pp[s] = pp[0]; }
+        const int p = pp[s];
+        const double *D0 = D + (size_t)p * CBB, *D1 = D0 + CBB, *E0 = E + (size_t)p * CBB;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int R = 4 * r + g;
+            const int hi = R > c8 ? R : c8, lo = R > c8 ? c8 : R;
+            wv[s][r] = *(left ? D0 + hi * CB + lo : E0 + c8 * CB + R);
+            wv[s][r + 2] = *(left ? E0 + R * CB + c8 : D1 + hi * CB + lo);
+        }
+        const bool side = p >= 1;
+        const double *Em = E + (size_t)(side ? p - 1 : 0) * CBB;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const double v = Em[(4 * r + g) * CB + c8];
+            sdv[s][r] = (side && left) ? v : 0.0;
+        }
+    }
+    // the elimination of this wavefront, if this wave holds it (at most one, the last item): its Q and E_j
+    int se = -1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) if (kind[s] == 2) se = s;
+    const bool has_x = se >= 0 && (jel + 1 <= N - 1);
+    if (se >= 0) {
+        const double *Qj = Qel + (size_t)jel * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qe[r] = Qj[(4 * r + g) * 16 + c];
+        const double *Ej = E + (size_t)(has_x ? jel : 0) * CBB;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const double v = Ej[c8 * CB + 4 * r + g];                 // (X^T)[8 + 4 r + g][c] = E_j[c][4 r + g]
+            xt[r] = (has_x && left) ? v : 0.0;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (kind[s] == 0) break;
+        const bool elim = kind[s] == 2;
+        const int p = pp[s];
+        double *D0 = D + (size_t)p * CBB, *D1 = D0 + CBB, *E0 = E + (size_t)p * CBB;
+        double q[4];
+        if (!elim) {
+            const double *qs = &Qs[wave][s][0];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q[r] = qs[(4 * r + g) * QLD + c];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q[r] = qe[r];
+        }
+        double4_t P = {0.0, 0.0, 0.0, 0.0}, Wn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P = cw_mfma(wv[s][r], q[r], P);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Wn = cw_mfma(q[r], P[r], Wn);
+        double4_t O = {0.0, 0.0, 0.0, 0.0};
+        O = cw_mfma(q[0], sdv[s][0], O);
+        O = cw_mfma(q[1], sdv[s][1], O);
+        if (left) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                D0[(4 * r + g) * CB + c8] = Wn[r];
+                E0[(4 * r + g) * CB + c8] = Wn[r + 2];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) D1[(4 * r + g) * CB + c8] = Wn[r + 2];
+        }
+        if (p >= 1 && left) {
+            double *Em = E + (size_t)(p - 1) * CBB, *Gm = G + (size_t)(p - 1) * CBB;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (!elim) Em[(4 * r + g) * CB + c8] = O[r];
+                Gm[(4 * r + g) * CB + c8] = O[r + 2];
+            }
+        }
+        if (elim && has_x) {
+            double4_t T = {0.0, 0.0, 0.0, 0.0};
+            T = cw_mfma(q[2], xt[0], T);
+            T = cw_mfma(q[3], xt[1], T);
+            if (left) {
+                double *Ej = E + (size_t)jel * CBB;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) Ej[c8 * CB + 4 * r + g] = T[r + 2];
+            }
+        }
+    }
+}
+
 // index-reversed overlap band: SBf[d][i] = S_f(i, i + d) = S(n-1-i-d, n-1-i)
 __global__ void crawford_flip_kernel(int n, int k, const double *__restrict__ SB, double *__restrict__ SBf)
 {
@@ -391,12 +623,17 @@ int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const doubl
         const int nch = (jhi >= jlo && jlo >= 2) ? jhi - jlo + 1 : 0;
         const int items = nch + (jel ? 1 : 0);
         if (items == 0) continue;
-        if (opts().cw_onediv)
-            hipLaunchKernelGGL(crawford_item_kernel<true>, dim3((items + 3) / 4, nl), dim3(256), 0, st, N, t, jlo, nch, jel, w.Qel, w.D,
-                               w.E, w.G);
-        else
-            hipLaunchKernelGGL(crawford_item_kernel<false>, dim3((items + 3) / 4, nl), dim3(256), 0, st, N, t, jlo, nch, jel, w.Qel, w.D,
-                               w.E, w.G);
+        if (opts().cw_items4) {
+            const int nw = opts().cw_nw == 4 ? 4 : 1;                      // waves per workgroup (A/B; a wave never talks to another)
+            const dim3 grid((items + 4 * nw - 1) / (4 * nw), nl), block(64 * nw);
+            if (opts().cw_onediv) hipLaunchKernelGGL((crawford_item4_kernel<true, 4>), dim3((items + 15) / 16, nl), dim3(256), 0, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E, w.G);
+            else if (nw == 4) hipLaunchKernelGGL((crawford_item4_kernel<false, 4>), grid, block, 0, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E, w.G);
+            else hipLaunchKernelGGL((crawford_item4_kernel<false, 1>), grid, block, 0, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E, w.G);
+        } else {
+            const dim3 grid((items + 3) / 4, nl);
+            if (opts().cw_onediv) hipLaunchKernelGGL(crawford_item_kernel<true>, grid, dim3(256), 0, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E, w.G);
+            else hipLaunchKernelGGL(crawford_item_kernel<false>, grid, dim3(256), 0, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E, w.G);
+        }
     }
     BSP_HIP(hipGetLastError());
     hipLaunchKernelGGL(crawford_band_kernel, dim3((npad * 32 + 255) / 256, nl), dim3(256), 0, st, n, npad, N, w.D, w.E, d_AB);

@@ -161,19 +161,26 @@ def test_sy2sb(npad, batch):
         assert np.max(np.abs(AB[b][:, 65:])) == 0.0
 
 
-@pytest.mark.parametrize("panel_qr", [3, 2])
+@pytest.mark.parametrize("panel_qr", [3, 2, 30, 31])
 @pytest.mark.parametrize("npad,c0,kind", [(128, 0, "rand"), (192, 0, "rand"), (256, 0, "rand"), (320, 0, "rand"), (384, 64, "rand"),
                                           (1152, 0, "graded"), (1152, 64, "rand"), (4096, 0, "rand"), (4160, 0, "graded"),
-                                          (640, 0, "rankdef"), (2048, 1472, "zero")])
+                                          (640, 0, "rankdef"), (2048, 1472, "zero"), (8384, 0, "rand")])
 def test_panel_factorisation(npad, c0, kind, panel_qr):
     """The panel factorisation of sy2sb alone (csrc/tsqr.hip: TSQR on many workgroups + Householder reconstruction,
     BSP_PANEL_QR=3; csrc/sy2sb.hip::panel_qr2_kernel + G + T + W, BSP_PANEL_QR=2) against its defining properties, as
     tools/proto_tsqr.py states them:  Q = I - W V^T (W = V T) orthogonal,  Q^T P = [R; 0] with R upper triangular = what the kernel
     left in the panel,  zeros below R.  Sizes: one block (m <= 256), one tree level (m <= 1024), two levels (m = 4032, 4096),
     ragged last blocks; a panel graded over 12 decades, one with 24 zero columns and zero padding rows (H = I reflectors), and an
-    all-zero panel.  Tolerances: a few ulp of ||P|| times sqrt(m)."""
+    all-zero panel.  Tolerances: a few ulp of ||P|| times sqrt(m).
+    panel_qr 30 / 31 (round-3 advisor): TSQR for EVERY panel (tsqr_max_m = 0: the two-level tree at m = 4032, 4096 that the rule
+    in m otherwise hands to the one-workgroup kernel) with the 256-register variants (30) and the uncapped ones (31,
+    tsqr_regcap = 0); npad = 8384 (m = 8320 > 8192: the deeper tree production takes there, ragged three-child nodes)."""
+    if npad > 8000 and panel_qr == 2:
+        pytest.skip("the one-workgroup kernels reach m <= 8192")
+    if npad < 1000 and panel_qr >= 30:
+        pytest.skip("small panels take TSQR under the default rule already (covered by panel_qr = 3)")
     rng = np.random.default_rng(npad + c0)
-    batch = 2
+    batch = 2 if npad < 8000 else 1
     m = npad - c0 - 64
     A = rng.standard_normal((batch, npad, npad))
     P = rng.standard_normal((batch, m, 64))
@@ -188,12 +195,16 @@ def test_panel_factorisation(npad, c0, kind, panel_qr):
         P[:] = 0.0
     A[:, c0 + 64:, c0:c0 + 64] = P
     A0 = A.copy()
-    old = capi.get_option("panel_qr")
-    capi.set_option("panel_qr", panel_qr)
+    old = {k_: capi.get_option(k_) for k_ in ("panel_qr", "tsqr_max_m", "tsqr_regcap")}
+    capi.set_option("panel_qr", 3 if panel_qr >= 30 else panel_qr)
+    if panel_qr >= 30:
+        capi.set_option("tsqr_max_m", 0)
+        capi.set_option("tsqr_regcap", 1 if panel_qr == 30 else 0)
     try:
         A1, V, W = capi.stage_panel(A, c0)
     finally:
-        capi.set_option("panel_qr", old)
+        for k_, v_ in old.items():
+            capi.set_option(k_, v_)
     # nothing but the panel is touched
     mask = np.ones((npad, npad), dtype=bool); mask[c0 + 64:, c0:c0 + 64] = False
     assert np.array_equal(A1[:, mask], A0[:, mask])

@@ -58,6 +58,41 @@ def rq_step(I, x0, x1, q):
     return x0, x1, q
 
 
+def rq4(X):
+    """crawford_item4_kernel's phase A for one item: X (8 x 16) -> (R part of X, Q 16 x 16), sums as four partial sums"""
+    x = np.zeros((16, 16)); x[:8] = X
+    q = np.eye(16)
+
+    def dot4(a, b, n):
+        ws = [0.0, 0.0, 0.0, 0.0]
+        for cc in range(n):
+            ws[cc & 3] = a[cc] * b[cc] + ws[cc & 3]
+        return (ws[0] + ws[1]) + (ws[2] + ws[3])
+    for I in range(7, -1, -1):
+        LEN = CB + I
+        u = x[I].copy()
+        sig = dot4(u, u, LEN); alpha = u[LEN]
+        a2s = alpha * alpha + sig
+        ok = a2s > 1e-280 and sig != 0.0
+        nrm = np.sqrt(a2s if ok else 1.0)
+        bt = -nrm if alpha >= 0 else nrm
+        amb = alpha - bt
+        sc = 1.0 / amb if ok else 0.0
+        tt = (bt - alpha) / bt if ok else 0.0
+        beta = bt if ok else alpha
+        u[:LEN] *= sc; u[LEN] = 1.0; u[LEN + 1:] = 0.0
+        for r in range(16):
+            w = dot4(x[r], u, LEN + 1)
+            tw = -tt * w if r <= I else 0.0
+            x[r, :LEN + 1] += tw * u[:LEN + 1]
+            w = dot4(q[r], u, LEN + 1)
+            q[r, :LEN + 1] += -tt * w * u[:LEN + 1]
+    return x[:8], q
+
+
+ITEMS4 = True
+
+
 def item(N, t, idx, jlo, nch, jel, Qel, D, E, G):
     if idx < nch:
         elim, j = False, jlo + idx; p = j - 2 - (t - 2 * j)
@@ -78,7 +113,13 @@ def item(N, t, idx, jlo, nch, jel, Qel, D, E, G):
         sd[r] = np.where(side & left, Em[(4 * r + g) * CB + c8], 0.0)
     q = np.zeros((4, 64)); xt = np.zeros((2, 64))
     has_x = elim and (j + 1 <= N - 1)
-    if not elim:
+    if not elim and ITEMS4:
+        X = np.hstack([G[p].reshape(8, 8), E[p + 1].reshape(8, 8)])
+        Xr, Qm = rq4(X)
+        x0 = Xr[g, c]; x1 = Xr[4 + g, c]
+        for r in range(4):
+            q[r] = Qm[4 * r + g, c]
+    elif not elim:
         src = np.where(left, G[p][(g * CB + c8)], E[p + 1][g * CB + c8])
         x0 = src
         x1 = np.where(left, G[p][((4 + g) * CB + c8)], E[p + 1][(4 + g) * CB + c8])
