@@ -35,7 +35,7 @@ EXPORTS = ["bspatom_input_defaults", "bspatom_device_count", "bspatom_host_setup
            "bspatom_problem_sizes", "bspatom_problem_grid", "bspatom_problem_route", "bspatom_assemble", "bspatom_solve", "bspatom_solve_dev",
            "bspatom_eigvec", "bspatom_eigvecs", "bspatom_dipole_bands", "bspatom_dipole_elements", "bspatom_write_wf", "bspatom_last_timing", "bsp_dsygv_", "bspatom_stage_gemm",
            "bspatom_stage_standard_form", "bspatom_stage_sy2sb", "bspatom_stage_panel", "bspatom_stage_sb2st", "bspatom_stage_sb2sb", "bspatom_stage_bisect", "bspatom_stage_crawford",
-           "bspatom_run_token", "bspatom_comm_create", "bspatom_comm_allgather", "bspatom_comm_collectives", "bspatom_comm_destroy",
+           "bspatom_release_scratch", "bspatom_run_token", "bspatom_comm_create", "bspatom_comm_allgather", "bspatom_comm_collectives", "bspatom_comm_destroy",
            "bspatom_set_option", "bspatom_get_option", "bspatom_kernel_times", "bspatom_kernel_slot_name"]
 
 _lib = None

@@ -44,18 +44,42 @@ void *pool_get(size_t bytes)
     g_pool.push_back({p, bytes, true});
     return p;
 }
+void pool_trim(size_t keep_bytes)
+{
+    // idle blocks go back to the driver, largest first, until at most keep_bytes stay parked
+    size_t idle = 0;
+    for (auto &b : g_pool) if (!b.used && b.p) idle += b.bytes;
+    while (idle > keep_bytes) {
+        int big = -1;
+        for (int i = 0; i < (int)g_pool.size(); ++i)
+            if (!g_pool[i].used && g_pool[i].p && (big < 0 || g_pool[i].bytes > g_pool[big].bytes)) big = i;
+        if (big < 0) break;
+        (void)hipFree(g_pool[big].p);
+        idle -= g_pool[big].bytes;
+        g_pool.erase(g_pool.begin() + big);
+    }
+}
 void pool_put(void *p)
 {
     if (!p) return;
-    for (auto &b : g_pool) if (b.p == p) { b.used = false; return; }
+    for (auto &b : g_pool) if (b.p == p) { b.used = false; break; }
+    // what a call leaves parked is bounded (round-3 advisor: the pool never returned memory and a later bspatom_problem_create
+    // in the same process could run out): 4 GiB covers the buffers of a repeated n = 8192 call; bspatom_release_scratch drops all
+    pool_trim((size_t)4 << 30);
 }
 }  // namespace
-
+extern "C" void bspatom_release_scratch(void)
+{
+    (void)hipDeviceSynchronize();
+    pool_trim(0);
+}
+namespace {
 template <class T> struct DBuf {
     T *p = nullptr;
     ~DBuf() { pool_put(p); }
     hipError_t alloc(size_t n) { p = static_cast<T *>(pool_get((n ? n : 1) * sizeof(T))); return p ? hipSuccess : hipErrorOutOfMemory; }
 };
+}  // namespace
 
 // ---- S-orthonormalisation of the eigenvectors inside clusters of close eigenvalues, on the GPU ---------------------------
 // Independent inverse iterations give Z^T S Z = I to ~eps |lambda|_max / gap; inside a cluster (neighbouring eigenvalues closer

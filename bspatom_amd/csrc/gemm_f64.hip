@@ -355,6 +355,7 @@ template <int BX, int LAY, bool SW = true>
 __device__ __forceinline__ void tile_store(const double2 (&r)[BK * BX / 512], double *S, int tid)
 {
     constexpr int LD = BX + 16;
+    static_assert(SW || LAY == 0, "the transposed store always permutes the columns: a kernel that reads plain rows (SW = false) may only stage along x");
 #pragma unroll
     for (int it = 0; it < BK * BX / 512; ++it) {
         const int idx = tid + it * 256;
@@ -496,8 +497,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #define G2_STORE_B(k0_, S_, rb)                                              \
     {                                                                        \
-        if (MODE == 2 && (k0_) >= ksw) tile_store<BN, 1, SW>(rb, S_, tid);   \
-        else tile_store<BN, BLAY, SW>(rb, S_, tid);                          \
+        if constexpr (MODE == 2) {                                           \
+            if ((k0_) >= ksw) tile_store<BN, 1, true>(rb, S_, tid);          \
+            else tile_store<BN, BLAY, SW>(rb, S_, tid);                      \
+        } else tile_store<BN, BLAY, SW>(rb, S_, tid);                        \
     }
     if (MODE == 1) {
         tile_load<BM, ALAY>(ra, A, g.sAm, g.sAk, m0, 0, g.M, g.K, tid);

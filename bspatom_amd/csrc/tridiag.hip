@@ -7,6 +7,7 @@
 //
 // count(x) = #{eigenvalues < x} from the LDL^T pivots q_i = (d_i - x) - e_{i-1}^2 / q_{i-1}
 // (LAPACK dstebz/dlaebz recurrence with the pivmin safeguard).
+#include <vector>
 #include "common.h"
 
 namespace bsp {
@@ -711,17 +712,22 @@ int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_
     while (bisect3_lds_bytes(nl, ng) > 150 * 1024) nl -= HW;
     const size_t lds3 = bisect3_lds_bytes(nl, ng);
     const size_t lds = (size_t)2 * (n + 3 * RS + HW) * sizeof(double);    // variants 1 and 2
-    static double2 *g_tail = nullptr;                                      // per process, grown on demand (stage-level scratch)
-    static size_t g_tail_cap = 0;
+    // rows beyond the LDS (n > 8672): one scratch array PER STREAM (launches of a stream are ordered, so a stream may reuse its
+    // own; two problems bisecting at the same time on their own streams no longer share rows -- round-3 advisor), grown on demand
+    struct Tail { hipStream_t st; double2 *p; size_t cap; };
+    static std::vector<Tail> g_tails;
     double2 *gtail = nullptr;
     if (nl < np3) {
         const size_t need = (size_t)batch * (np3 + 1);
-        if (need > g_tail_cap) {
-            if (g_tail) { BSP_HIP(hipStreamSynchronize(st)); (void)hipFree(g_tail); g_tail = nullptr; g_tail_cap = 0; }
-            BSP_HIP(hipMalloc(reinterpret_cast<void **>(&g_tail), need * sizeof(double2)));
-            g_tail_cap = need;
+        Tail *tl = nullptr;
+        for (auto &x : g_tails) if (x.st == st) tl = &x;
+        if (!tl) { g_tails.push_back({st, nullptr, 0}); tl = &g_tails.back(); }
+        if (need > tl->cap) {
+            if (tl->p) { BSP_HIP(hipStreamSynchronize(st)); (void)hipFree(tl->p); tl->p = nullptr; tl->cap = 0; }
+            BSP_HIP(hipMalloc(reinterpret_cast<void **>(&tl->p), need * sizeof(double2)));
+            tl->cap = need;
         }
-        gtail = g_tail;
+        gtail = tl->p;
         if (opts().bisect < 3) return BSP_ERR_UNSUPPORTED;                  // the older counting kernels keep the whole matrix in LDS
     }
     static bool attr_set = false;

@@ -167,6 +167,10 @@ void bsp_dsygv_(const int *itype, const char *jobz, const char *uplo, const int 
                 const int *lda, double *b, const int *ldb, double *w, double *work, const int *lwork,
                 int *info, size_t jobz_len, size_t uplo_len);
 
+/* bsp_dsygv_ keeps its device buffers in a process-wide pool between calls (the reference calls DSYGV once per l in a loop); at
+ * most 4 GiB stay parked after a call.  This returns every idle buffer of that pool to the driver. */
+void bspatom_release_scratch(void);
+
 /* ---- run-time switches (tests, A/B comparisons) ----------------------------------------------- */
 /* The BSP_* environment variables of DESIGN.md 4.4 are read once per process; these two calls read and
  * change the same switches afterwards, by lower-case name without the prefix ("sb2st_ring",
