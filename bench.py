@@ -516,7 +516,7 @@ def report(args, world, n, npad, main, ktimes, kstage, route):
         if calls:
             ach = fb["band_reduction"] * nl / (ms_sum * 1e-3) / 1e12
             items = (N - 1) * (N - 2) // 2
-            kern.append({"kernel": "crawford_item_kernel (+ its set-up kernels; csrc/crawford.hip)", "what": "banded pencil -> band 15: "
+            kern.append({"kernel": "crawford_item4_kernel (+ its set-up kernels; crawford_item_kernel with BSP_CW_ITEMS4=0; csrc/crawford.hip)", "what": "banded pencil -> band 15: "
                          "%d chase items of 8 x 8 blocks per channel in %d wavefront launches" % (items, 3 * N - 5), "bound": "mfma",
                          "launches_per_step": 3 * N - 5 + 5, "kernel_ms_per_step": ms_sum, "avg_launch_ms": ms_sum / (3 * N),
                          "launch_ms_source": "HIP events around the whole stage, one extra untimed step of this run (bspatom_kernel_times)",
@@ -525,8 +525,9 @@ def report(args, world, n, npad, main, ktimes, kstage, route):
                          "bytes_model_definition": "11 blocks of 512 B read or written per item (mostly L2 / Infinity Cache hits: the working "
                                                    "set of a channel is 0.8 MB)",
                          "traffic": pmc_bytes("crawford_item"), "traffic_source": pmc_file, "traffic_stale": pmc_stale,
-                         "limited_by": "fp64 issue: ~1400 vector instructions per item, a third of them the DPP moves of 16-lane row sums; "
-                                       "the MFMA congruences are 12 of them"})
+                         "limited_by": "issue and latency at two waves per SIMD (250 registers): ~640 instructions per item, the serial sqrt / "
+                                       "division chain of eight reflectors, 12 fp64 MFMAs (on gfx950 an fp64 MFMA costs what its 1024 "
+                                       "multiply-adds cost on the vector pipe); wavefront launches quantise the occupancy"})
         ms_sum, calls = kt("sb16")
         b2 = sum(2 * 32 * 8 * (n - s0_) for s0_ in range(0, n - 2, 8)) * nl
         if calls:

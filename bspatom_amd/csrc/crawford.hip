@@ -367,6 +367,13 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
         for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2 *>(qs + c) = make_double2(q[c], q[c + 1]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this wave's own LDS stores (no other wave reads them)
+    // Everything phase B computes from the kernel's arguments (item numbers, block addresses of four items) would otherwise be
+    // hoisted in front of phase A and sit in registers across it (96 dwords spilled at three waves per SIMD): the two values it
+    // all derives from are redefined here, as far as the compiler can tell.
+    int idx0b = idx0;
+    size_t chnb = chn;
+    asm volatile("" : "+s"(idx0b), "+s"(chnb));
+    D = Dall + chnb; E = Eall + chnb; G = Gall + chnb;
 
     // ---- phase B: the congruences, one item at a time, in the layout of the matrix cores.  The operands of all four items are
     // requested before the first product (a slot without an item reads slot 0's addresses and is skipped): one round trip to
@@ -377,9 +384,9 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
     double wv[4][4], sdv[4][2], qe[4], xt[2] = {0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const int idx = idx0 + s;
+        const int idx = idx0b + s;
         kind[s] = idx < nch ? 1 : ((idx == nch && jel > 0) ? 2 : 0);
-        jj[s] = kind[s] == 1 ? jlo + idx : (kind[s] == 2 ? jel : jlo + idx0);
+        jj[s] = kind[s] == 1 ? jlo + idx : (kind[s] == 2 ? jel : jlo + idx0b);
         pp[s] = kind[s] == 2 ? jel - 1 : jj[s] - 2 - (t - 2 * jj[s]);
         if (kind[s] == 0) { jj[s] = jj[0]; pp[s] = pp[0]; }
         const int p = pp[s];
