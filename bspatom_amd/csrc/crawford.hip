@@ -476,179 +476,6 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------
-// crawford_rows_kernel: the chase item WITHOUT its Q and without the matrix cores.  crawford_item4_kernel accumulates the 16 x 16
-// factor Q row by row (16 rows x 8 reflectors) only to hand it to twelve fp64 MFMAs -- which on gfx950 cost what their
-// multiply-adds cost on the vector pipe.  In the row layout the congruence itself is two more row-wise applications of the same
-// reflectors: lane r of an item's DPP row holds row r of the window W; pass 1 applies every reflector, as it is formed, on the
-// right of X (rows <= I), of W (all 16 rows) and of the transposed block in front ([E_{p-1}; 0]^T, 8 rows): W1 = W Q.  W1 goes
-// through LDS once (each lane writes its row and reads its column), pass 2 applies the stored reflectors to the rows of W1^T:
-// W1^T Q = (Q^T W Q)^T = W' (symmetric), so lane r ends with row r of W' and stores its halves of D_p, E_p, D_{p+1} as whole
-// rows.  ~375 vector instructions per item instead of ~640 + 12 MFMAs (= 190 more); one wave = four items, one wave per
-// workgroup.  D blocks are read and written as full rows here (both triangles are kept and agree to rounding; the
-// elimination items, which stay on crawford_item_kernel -- one per wavefront and channel, a launch of their own -- read the
-// lower triangle).
-constexpr int RT = 18;                                                   // row stride (doubles) of the transposition tile
-
-// One reflector of pass 1 / pass 2, compile-time length 9 + I.  The eight steps are the cases of a switch inside a loop that is
-// NOT unrolled: each step is a basic block of its own, so the scheduler cannot interleave them (fully unrolled in one block the
-// kernel needs 444 registers -- one wave per SIMD; with a run-time I and full-length loops it is 153 registers and 22 % more
-// FMAs plus the selects of the length: slower than crawford_item4_kernel).
-template <int I, bool ONEDIV>
-__device__ __forceinline__ void rows_step1(double (&x)[16], double (&w)[16], double &tI, double *bc, double *us, const int r)
-{
-    constexpr int LEN = CB + I;
-    if (r == I) {
-#pragma unroll
-        for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2 *>(bc + c) = make_double2(x[c], x[c + 1]);
-    }
-    asm volatile("" ::: "memory");                                      // other lanes read what lane I stored (see rq4_step)
-    double u[16];
-#pragma unroll
-    for (int c = 0; c < 16; c += 2) {
-        if (c <= LEN) {
-            const double2 v = *reinterpret_cast<const double2 *>(bc + c);
-            u[c] = v.x; u[c + 1] = v.y;
-        }
-    }
-    asm volatile("" ::: "memory");
-    double sg[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int c = 0; c < LEN; ++c) sg[c & 3] = fma(u[c], u[c], sg[c & 3]);
-    const double sig = (sg[0] + sg[1]) + (sg[2] + sg[3]);
-    const double alpha = u[LEN];
-    const double a2s = fma(alpha, alpha, sig);
-    const bool ok = (a2s > 1e-280) && (sig != 0.0);
-    const double nrm = sqrt(ok ? a2s : 1.0);
-    const double bt = (alpha >= 0.0) ? -nrm : nrm;
-    const double amb = alpha - bt;
-    const double sc = ONEDIV ? 1.0 : (ok ? 1.0 / amb : 0.0);
-    const double t = ok ? (ONEDIV ? -1.0 / (bt * amb) : (bt - alpha) / bt) : 0.0;
-    if (!ONEDIV) {
-#pragma unroll
-        for (int c = 0; c < LEN; ++c) u[c] *= sc;
-    }
-    u[LEN] = ONEDIV ? amb : 1.0;
-    if (LEN + 1 < 16) u[LEN + 1] = 0.0;                                  // the pair that is stored with the pivot
-    tI = t;
-    if (r == I) {                                                       // the reflector for pass 2 (one lane of the row writes it)
-#pragma unroll
-        for (int c = 0; c < 16; c += 2)
-            if (c <= LEN) *reinterpret_cast<double2 *>(us + c) = make_double2(u[c], u[c + 1]);
-    }
-#define ROWS_APPLY(v, cond)                                                              \
-    {                                                                                    \
-        double ws[4] = {0.0, 0.0, 0.0, 0.0};                                             \
-        _Pragma("unroll") for (int c = 0; c <= LEN; ++c) ws[c & 3] = fma(v[c], u[c], ws[c & 3]); \
-        const double tw = (cond) ? -t * ((ws[0] + ws[1]) + (ws[2] + ws[3])) : 0.0;       \
-        _Pragma("unroll") for (int c = 0; c <= LEN; ++c) v[c] = fma(tw, u[c], v[c]);     \
-    }
-    ROWS_APPLY(x, r <= I)
-    ROWS_APPLY(w, true)
-}
-
-// pass 2: the stored reflector on the rows of W1^T (all lanes) and of the transposed block in front (lanes < 8)
-template <int I>
-__device__ __forceinline__ void rows_step2(double (&w)[16], double (&st)[16], const double t, const double *us, const int r)
-{
-    constexpr int LEN = CB + I;
-    double u[16];
-#pragma unroll
-    for (int c = 0; c < 16; c += 2) {
-        if (c <= LEN) {
-            const double2 v = *reinterpret_cast<const double2 *>(us + c);
-            u[c] = v.x; u[c + 1] = v.y;
-        }
-    }
-    ROWS_APPLY(w, true)
-    ROWS_APPLY(st, r < CB)
-#undef ROWS_APPLY
-}
-
-template <bool ONEDIV>
-__global__ __launch_bounds__(64) void crawford_rows_kernel(int N, int t, int jlo, int nch, double *Dall, double *Eall, double *Gall)
-{
-    __shared__ __attribute__((aligned(16))) double Bc[4][16];            // the row that goes round, per item slot
-    __shared__ __attribute__((aligned(16))) double Us[4][CB][16];        // the reflectors of pass 1 for pass 2
-    __shared__ __attribute__((aligned(16))) double Tr[4][16 * RT];       // transposition tile
-    const int lane = threadIdx.x, it = lane >> 4, r = lane & 15, r8 = r & 7;
-    const int idx0 = blockIdx.x * 4;
-    if (idx0 >= nch) return;
-    const size_t chn = (size_t)blockIdx.y * N * CBB;
-    double *D = Dall + chn, *E = Eall + chn, *G = Gall + chn;
-    const int idx = idx0 + it;
-    const bool item = idx < nch, top = r < CB;                          // top: lanes that hold a row of X and of the block in front
-    const int j = jlo + (item ? idx : 0), p = j - 2 - (t - 2 * j);
-    const bool side = p >= 1;
-    double *D0 = D + (size_t)p * CBB, *D1 = D0 + CBB, *E0 = E + (size_t)p * CBB, *E1 = E0 + CBB;
-    double *Em = E + (size_t)(side ? p - 1 : 0) * CBB, *Gm = G + (size_t)(side ? p - 1 : 0) * CBB;
-    double x[16], w[16], ts[CB];
-    {
-        // rows 0 .. 7 of the window: [D_p row | column r of E_p]; rows 8 .. 15: [E_p row | D_{p+1} row]
-        const double *wa = top ? D0 + r8 * CB : E0 + r8 * CB;
-        const double *wb = top ? E0 + r8 : D1 + r8 * CB;
-        const int sb = top ? CB : 1;
-        const double *gp = G + (size_t)p * CBB + r8 * CB, *ep = E1 + r8 * CB;
-#pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            const double a = wa[c], b = wb[c * sb], f = gp[c], e = ep[c];
-            w[c] = item ? a : 0.0; w[CB + c] = item ? b : 0.0;
-            x[c] = (item && top) ? f : 0.0; x[CB + c] = (item && top) ? e : 0.0;
-        }
-    }
-    double *bc = &Bc[it][0];
-#pragma unroll 1
-    for (int I = CB - 1; I >= 0; --I) {
-        switch (I) {
-#define CASE1(K) case K: rows_step1<K, ONEDIV>(x, w, ts[K], bc, &Us[it][K][0], r); break;
-            CASE1(7) CASE1(6) CASE1(5) CASE1(4) CASE1(3) CASE1(2) CASE1(1) CASE1(0)
-#undef CASE1
-        }
-    }
-    if (item && top) {                                                   // E_{p+1} <- R
-#pragma unroll
-        for (int c = 0; c < CB; c += 2) *reinterpret_cast<double2 *>(E1 + r * CB + c) = make_double2(x[CB + c], x[CB + c + 1]);
-    }
-    // W1 = W Q, transposed through LDS
-    {
-        double *tr = &Tr[it][0];
-#pragma unroll
-        for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2 *>(tr + r * RT + c) = make_double2(w[c], w[c + 1]);
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int c = 0; c < 16; ++c) w[c] = tr[c * RT + r];
-        asm volatile("" ::: "memory");
-    }
-    // the block in front, transposed: row i (lane i < 8) = column i of [E_{p-1}; 0]; it takes the reflectors in pass 2
-    double st[16];
-#pragma unroll
-    for (int c = 0; c < CB; ++c) {
-        const double m = Em[c * CB + r8];
-        st[c] = (item && top && side) ? m : 0.0; st[CB + c] = 0.0;
-    }
-#pragma unroll 1
-    for (int I = CB - 1; I >= 0; --I) {
-        switch (I) {
-#define CASE2(K) case K: rows_step2<K>(w, st, ts[K], &Us[it][K][0], r); break;
-            CASE2(7) CASE2(6) CASE2(5) CASE2(4) CASE2(3) CASE2(2) CASE2(1) CASE2(0)
-#undef CASE2
-        }
-    }
-    if (item && top && side) {                                           // columns of [E_{p-1}'; F'] are the rows held here
-#pragma unroll
-        for (int c = 0; c < CB; ++c) { Em[c * CB + r] = st[c]; Gm[c * CB + r] = st[CB + c]; }
-    }
-    if (item) {
-        double *da = top ? D0 + r8 * CB : E0 + r8 * CB;                   // columns 0 .. 7 of row r of W'
-#pragma unroll
-        for (int c = 0; c < CB; c += 2) *reinterpret_cast<double2 *>(da + c) = make_double2(w[c], w[c + 1]);
-        if (!top) {
-#pragma unroll
-            for (int c = 0; c < CB; c += 2) *reinterpret_cast<double2 *>(D1 + r8 * CB + c) = make_double2(w[CB + c], w[CB + c + 1]);
-        }
-    }
-}
-
 // index-reversed overlap band: SBf[d][i] = S_f(i, i + d) = S(n-1-i-d, n-1-i)
 __global__ void crawford_flip_kernel(int n, int k, const double *__restrict__ SB, double *__restrict__ SBf)
 {
@@ -803,18 +630,7 @@ int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const doubl
         const int nch = (jhi >= jlo && jlo >= 2) ? jhi - jlo + 1 : 0;
         const int items = nch + (jel ? 1 : 0);
         if (items == 0) continue;
-        if (opts().cw_items4 == 2) {
-            // chase items in the row layout (no Q, no MFMA); the wavefront's elimination, if any, as a launch of the first kernel
-            if (nch > 0) {
-                const dim3 grid((nch + 3) / 4, nl);
-                if (opts().cw_onediv) hipLaunchKernelGGL(crawford_rows_kernel<true>, grid, dim3(64), 0, st, N, t, jlo, nch, w.D, w.E, w.G);
-                else hipLaunchKernelGGL(crawford_rows_kernel<false>, grid, dim3(64), 0, st, N, t, jlo, nch, w.D, w.E, w.G);
-            }
-            if (jel) {
-                if (opts().cw_onediv) hipLaunchKernelGGL(crawford_item_kernel<true>, dim3(1, nl), dim3(256), 0, st, N, t, jlo, 0, jel, w.Qel, w.D, w.E, w.G);
-                else hipLaunchKernelGGL(crawford_item_kernel<false>, dim3(1, nl), dim3(256), 0, st, N, t, jlo, 0, jel, w.Qel, w.D, w.E, w.G);
-            }
-        } else if (opts().cw_items4) {
+        if (opts().cw_items4) {
             const int nw = opts().cw_nw == 4 ? 4 : 1;                      // waves per workgroup (A/B; a wave never talks to another)
             const dim3 grid((items + 4 * nw - 1) / (4 * nw), nl), block(64 * nw);
             if (opts().cw_onediv) hipLaunchKernelGGL((crawford_item4_kernel<true, 1>), dim3((items + 3) / 4, nl), dim3(64), 0, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E, w.G);

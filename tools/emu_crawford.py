@@ -91,68 +91,6 @@ def rq4(X):
 
 
 ITEMS4 = True
-ROWS = True          # crawford_rows_kernel: no Q, no MFMA; the congruence as two row-wise passes with a transposition in between
-
-
-def item_rows(p, D, E, G):
-    """crawford_rows_kernel for one chase item (window p): the kernel's loads, sums (four partial sums over 16 entries, zeros
-    beyond the pivot riding along) and stores"""
-    side = p >= 1
-    x = np.zeros((16, 16)); w = np.zeros((16, 16))
-    for r in range(16):
-        r8 = r & 7
-        if r < 8:
-            x[r, :8] = G[p][r8 * 8:r8 * 8 + 8]; x[r, 8:] = E[p + 1][r8 * 8:r8 * 8 + 8]
-            w[r, :8] = D[p][r8 * 8:r8 * 8 + 8]; w[r, 8:] = E[p][r8::8][:8]           # column r of E_p
-        else:
-            w[r, :8] = E[p][r8 * 8:r8 * 8 + 8]; w[r, 8:] = D[p + 1][r8 * 8:r8 * 8 + 8]
-
-    def dot4(a, b):
-        ws = [0.0, 0.0, 0.0, 0.0]
-        for cc in range(16):
-            ws[cc & 3] = a[cc] * b[cc] + ws[cc & 3]
-        return (ws[0] + ws[1]) + (ws[2] + ws[3])
-    us = np.zeros((8, 16)); ts = np.zeros(8)
-    for I in range(7, -1, -1):
-        LEN = CB + I
-        u = x[I].copy(); u[LEN + 1:] = 0.0
-        alpha = u[LEN]
-        v = u.copy(); v[LEN:] = 0.0
-        sig = dot4(v, v)
-        a2s = alpha * alpha + sig
-        ok = a2s > 1e-280 and sig != 0.0
-        nrm = np.sqrt(a2s if ok else 1.0)
-        bt = -nrm if alpha >= 0 else nrm
-        amb = alpha - bt
-        sc = 1.0 / amb if ok else 0.0
-        tt = (bt - alpha) / bt if ok else 0.0
-        u = u * sc; u[LEN] = 1.0
-        us[I] = u; ts[I] = tt
-        for r in range(16):
-            if r <= I:
-                x[r] += (-tt * dot4(x[r], u)) * u
-            w[r] += (-tt * dot4(w[r], u)) * u
-    E[p + 1][:] = x[:8, 8:].reshape(-1)
-    w = w.T.copy()
-    st = np.zeros((16, 16))
-    if side:
-        for i in range(8):
-            st[i, :8] = E[p - 1][i::8][:8]
-    for I in range(7, -1, -1):
-        for r in range(16):
-            w[r] += (-ts[I] * dot4(w[r], us[I])) * us[I]
-            if r < 8:
-                st[r] += (-ts[I] * dot4(st[r], us[I])) * us[I]
-    if side:
-        for r in range(8):
-            for cc in range(8):
-                E[p - 1][cc * 8 + r] = st[r, cc]; G[p - 1][cc * 8 + r] = st[r, 8 + cc]
-    for r in range(16):
-        r8 = r & 7
-        if r < 8:
-            D[p][r8 * 8:r8 * 8 + 8] = w[r, :8]
-        else:
-            E[p][r8 * 8:r8 * 8 + 8] = w[r, :8]; D[p + 1][r8 * 8:r8 * 8 + 8] = w[r, 8:]
 
 
 def item(N, t, idx, jlo, nch, jel, Qel, D, E, G):
@@ -161,9 +99,6 @@ def item(N, t, idx, jlo, nch, jel, Qel, D, E, G):
     elif idx == nch and jel > 0:
         elim, j = True, jel; p = j - 1
     else:
-        return
-    if ROWS and not elim:
-        item_rows(p, D, E, G)
         return
     D0, D1, E0 = D[p], D[p + 1], E[p]
     w = np.zeros((4, 64)); sd = np.zeros((2, 64))
