@@ -625,3 +625,22 @@ def test_accuracy_ratchet_file_only_tightens():
             assert route in ("route1", "route2"), (name, route)
             for fig, o in figs.items():
                 assert fig in GATED and o["bar"] >= o["measured"] and len(o["why"]) > 40, (name, route, fig)
+
+
+def test_run_token_names_the_launch():
+    """bspatom_run_token (csrc/comm.hip): the id that names the exchange files and the ncclUniqueId file of one launch -- "<pid of
+    the launcher>.<its start time>": the same in every child of one parent, the parent's pid in front, another value for a child
+    of another parent.  (No GPU needed: the call touches /proc only.)"""
+    import subprocess, sys
+    code = ("import ctypes, os, sys; sys.path.insert(0, %r); from bspatom_amd import capi; b = ctypes.create_string_buffer(128); "
+            "assert capi.lib().bspatom_run_token(b, 128) == 0; print(os.getppid(), b.value.decode())" % ROOT)
+    outs = [subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120) for _ in range(2)]
+    for o in outs:
+        assert o.returncode == 0, o.stderr
+    (pp1, t1), (pp2, t2) = [o.stdout.split() for o in outs]
+    assert pp1 == pp2 == str(os.getpid()) and t1 == t2 and t1.split(".")[0] == pp1 and int(t1.split(".")[1]) > 0
+    # a child of another parent (a shell in between) gets another token
+    o3 = subprocess.run(["sh", "-c", "%s -c %s; true" % (sys.executable, "'" + code.replace("'", '"') + "'")], capture_output=True, text=True, timeout=120)
+    assert o3.returncode == 0 and o3.stdout.split()[1] != t1, o3.stdout + o3.stderr
+    b = __import__("ctypes").create_string_buffer(4)
+    assert capi.lib().bspatom_run_token(b, 4) != 0                     # a buffer that cannot hold it is an argument error
