@@ -1182,10 +1182,12 @@ def test_sb2st_handoff_under_uneven_load(tmp_path):
     prob = capi.Problem(input_from_case("c4_4096", l_fin=127))
     # (channels, ring, generation): the default two-step route (9: pairs of workgroups share the passes of its second step at 128
     # channels, rings of 8 / 4 at 32) and the one-step route (8)
-    cases = ((128, 0, 9), (32, 8, 9), (32, 4, 9), (128, 0, 8), (32, 8, 8), (32, 4, 8))
+    # ... and (version 0 here) the band route, whose band-16 chase hands over the same way and whose wavefront launches must not care
+    cases = ((128, 0, 9), (32, 8, 9), (32, 4, 9), (128, 0, 8), (32, 8, 8), (32, 4, 8), (128, 0, 0), (32, 8, 0), (32, 4, 0))
     quiet, tq = {}, {}
+    opts_of = lambda ring, ver: dict(sb2st_ring=ring, route=2) if ver == 0 else dict(sb2st_ring=ring, sb2st_version=ver, route=1)
     for nl, ring, ver in cases:
-        with _Options(sb2st_ring=ring, sb2st_version=ver):
+        with _Options(**opts_of(ring, ver)):
             quiet[(nl, ring, ver)], info = prob.solve(0, nl)
         tq[(nl, ring, ver)] = prob.last_timing()["sb2st"]
         assert np.all(info == 0)
@@ -1201,7 +1203,7 @@ def test_sb2st_handoff_under_uneven_load(tmp_path):
         tn = {}
         for rep in range(2):
             for nl, ring, ver in cases:
-                with _Options(sb2st_ring=ring, sb2st_version=ver):
+                with _Options(**opts_of(ring, ver)):
                     E, info = prob.solve(0, nl)
                 tn[(nl, ring, ver)] = prob.last_timing()["sb2st"]
                 assert np.all(info == 0)
