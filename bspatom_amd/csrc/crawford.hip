@@ -635,7 +635,7 @@ int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const doubl
             const dim3 grid((items + 4 * nw - 1) / (4 * nw), nl), block(64 * nw);
             if (opts().cw_onediv) hipLaunchKernelGGL((crawford_item4_kernel<true, 1>), dim3((items + 3) / 4, nl), dim3(64), 0, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E, w.G);
             else if (nw == 4) hipLaunchKernelGGL((crawford_item4_kernel<false, 4>), grid, block, 0, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E, w.G);
-            else hipLaunchKernelGGL((crawford_item4_kernel<false, 1>), grid, block, 0, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E, w.G);
+            else hipLaunchKernelGGL((crawford_item4_kernel<false, 1>), grid, block, (size_t)opts().cw_ldspad * 1024, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E, w.G);
         } else {
             const dim3 grid((items + 3) / 4, nl);
             if (opts().cw_onediv) hipLaunchKernelGGL(crawford_item_kernel<true>, grid, dim3(256), 0, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E, w.G);
