@@ -67,6 +67,7 @@ struct Options {
     int cw_items4 = 1;           // BSP_CW_ITEMS4: 1 = crawford_item4_kernel (four chase items per wave, an item per DPP row in the RQ loop),
                                  // 0 = crawford_item_kernel (one item per wave; the cross-check)
     int cw_nw = 1;               // BSP_CW_NW: waves per workgroup of crawford_item4_kernel (1 or 4; a wave never talks to another)
+    int cw_ipw = 0;              // BSP_CW_IPW: items per wave of crawford_item4_kernel (0 = 4; 1, 2: experiment 9; bit-identical results)
     int cw_ldspad = 0;           // BSP_CW_LDSPAD: KB of unused dynamic LDS per workgroup of crawford_item4_kernel (timing experiment: occupancy)
     int cw_onediv = 0;           // BSP_CW_ONEDIV: reflectors of the band route's RQ loop in the one-division form (A/B switch)
     int ktime = 0;               // 1: HIP events around every launch of the kernels in KSlot (bspatom_kernel_times; bench.py's

@@ -317,14 +317,16 @@ __device__ __forceinline__ void rq4_step(double (&x)[16], double (&q)[16], doubl
 }
 
 template <bool ONEDIV, int NW>
-__global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, int t, int jlo, int nch, int jel,
+__global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, int t, int jlo, int nch, int jel, int ipw,
                                                             const double *__restrict__ Qel, double *Dall, double *Eall, double *Gall)
 {
     __shared__ __attribute__((aligned(16))) double Qs[NW][4][16 * QLD];  // per wave and item slot: Q, row-major, stride QLD
     __shared__ __attribute__((aligned(16))) double Bc[NW][4][16];        // per wave and item slot: the row that goes round
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int idx0 = (blockIdx.x * NW + wave) * 4;                       // first of this wave's four items
+    // ipw = items per wave: 4; 2 or 1 only as an experiment (BSP_CW_IPW).  An item's arithmetic does not depend on the slot it
+    // sits in: the choice changes no bit (tests/test_gpu_solve.py::test_band_route_properties).
+    const int idx0 = (blockIdx.x * NW + wave) * ipw;                     // first of this wave's items
     const int items = nch + (jel > 0 ? 1 : 0);
     if (idx0 >= items) return;
     const size_t chn = (size_t)blockIdx.y * N * CBB;
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
     if (idx0 < nch) {
         const int it = lane >> 4, r = lane & 15;
         const int idx = idx0 + it;
-        const bool live = idx < nch && r < CB;                           // lanes that hold a row of X
+        const bool live = idx < nch && it < ipw && r < CB;               // lanes that hold a row of X
         const int j = jlo + (idx < nch ? idx : 0), p = j - 2 - (t - 2 * j);
         double x[16], q[16];
         {
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int idx = idx0b + s;
-        kind[s] = idx < nch ? 1 : ((idx == nch && jel > 0) ? 2 : 0);
+        kind[s] = s >= ipw ? 0 : (idx < nch ? 1 : ((idx == nch && jel > 0) ? 2 : 0));
         jj[s] = kind[s] == 1 ? jlo + idx : (kind[s] == 2 ? jel : jlo + idx0b);
         pp[s] = kind[s] == 2 ? jel - 1 : jj[s] - 2 - (t - 2 * jj[s]);
         if (kind[s] == 0) { jj[s] = jj[0]; pp[s] = pp[0]; }
@@ -632,10 +634,15 @@ int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const doubl
         if (items == 0) continue;
         if (opts().cw_items4) {
             const int nw = opts().cw_nw == 4 ? 4 : 1;                      // waves per workgroup (A/B; a wave never talks to another)
-            const dim3 grid((items + 4 * nw - 1) / (4 * nw), nl), block(64 * nw);
-            if (opts().cw_onediv) hipLaunchKernelGGL((crawford_item4_kernel<true, 1>), dim3((items + 3) / 4, nl), dim3(64), 0, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E, w.G);
-            else if (nw == 4) hipLaunchKernelGGL((crawford_item4_kernel<false, 4>), grid, block, 0, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E, w.G);
-            else hipLaunchKernelGGL((crawford_item4_kernel<false, 1>), grid, block, (size_t)opts().cw_ldspad * 1024, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E, w.G);
+            // items per wave: as few as still fit the chip in one round of resident waves (two per SIMD: 2048)
+            // four items per wave at every launch size: fewer (BSP_CW_IPW = 1, 2) on the launches that would still fit the chip
+            // was measured and is slower (profiles/r04_experiments.txt, 9) -- a wave's RQ loop costs the same for one item as for four
+            const int ipw = (opts().cw_ipw == 1 || opts().cw_ipw == 2) ? opts().cw_ipw : 4;
+            const int waves = (items + ipw - 1) / ipw;
+            const dim3 grid((waves + nw - 1) / nw, nl), block(64 * nw);
+            if (opts().cw_onediv) hipLaunchKernelGGL((crawford_item4_kernel<true, 1>), dim3(waves, nl), dim3(64), 0, st, N, t, jlo, nch, jel, ipw, w.Qel, w.D, w.E, w.G);
+            else if (nw == 4) hipLaunchKernelGGL((crawford_item4_kernel<false, 4>), grid, block, 0, st, N, t, jlo, nch, jel, ipw, w.Qel, w.D, w.E, w.G);
+            else hipLaunchKernelGGL((crawford_item4_kernel<false, 1>), grid, block, (size_t)opts().cw_ldspad * 1024, st, N, t, jlo, nch, jel, ipw, w.Qel, w.D, w.E, w.G);
         } else {
             const dim3 grid((items + 3) / 4, nl);
             if (opts().cw_onediv) hipLaunchKernelGGL(crawford_item_kernel<true>, grid, dim3(256), 0, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E, w.G);

@@ -1,7 +1,9 @@
 #!/bin/bash
 set -o pipefail
 O=gpurun_out/r4k; mkdir -p $O; rm -f $O/times.txt
-for pad in 0 12 30 70; do
-  timeout -k 10 200 python tools/stage_times.py --channels 128 --reps 3 cw_ldspad=$pad >> $O/times.txt 2>> $O/err.txt || { tail -5 $O/err.txt; exit 1; }
-done
+timeout -k 10 600 python -m pytest tests/test_gpu_solve.py tests/test_gpu_stages.py -x -q -k "band_route or crawford" > $O/pytest.log 2>&1 || { tail -30 $O/pytest.log | cut -c1-300; exit 1; }
+tail -1 $O/pytest.log
+for ch in 128 64 32 16; do for v in "cw_ipw=4" "cw_ipw=0"; do
+  timeout -k 10 200 python tools/stage_times.py --channels $ch --reps 5 $v >> $O/times.txt 2>> $O/err.txt || { tail -5 $O/err.txt; exit 1; }
+done; done
 cat $O/times.txt
