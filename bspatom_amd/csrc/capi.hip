@@ -78,7 +78,7 @@ const OptName OPT_TABLE[] = {
     {"poison_c", "BSP_POISON_C", &Options::poison_c}, {"sb2sb_mfma", "BSP_SB2SB_MFMA", &Options::sb2sb_mfma},
     {"ktime", "BSP_KTIME", &Options::ktime}, {"tsqr_regcap", "BSP_TSQR_REGCAP", &Options::tsqr_regcap},
     {"tsqr_max_m", "BSP_TSQR_MAX_M", &Options::tsqr_max_m}, {"sb16_rows", "BSP_SB16_ROWS", &Options::sb16_rows},
-    {"route", "BSP_ROUTE", &Options::route}, {"cw_onediv", "BSP_CW_ONEDIV", &Options::cw_onediv}, {"cw_items4", "BSP_CW_ITEMS4", &Options::cw_items4}, {"cw_nw", "BSP_CW_NW", &Options::cw_nw}, {"cw_ldspad", "BSP_CW_LDSPAD", &Options::cw_ldspad}, {"cw_ipw", "BSP_CW_IPW", &Options::cw_ipw},
+    {"route", "BSP_ROUTE", &Options::route}, {"cw_onediv", "BSP_CW_ONEDIV", &Options::cw_onediv}, {"cw_items4", "BSP_CW_ITEMS4", &Options::cw_items4}, {"cw_nw", "BSP_CW_NW", &Options::cw_nw}, {"cw_ldspad", "BSP_CW_LDSPAD", &Options::cw_ldspad}, {"cw_ipw", "BSP_CW_IPW", &Options::cw_ipw}, {"cw_band8", "BSP_CW_BAND8", &Options::cw_band8}, {"sb8_wgs", "BSP_SB8_WGS", &Options::sb8_wgs},
     {"fused_probe", "BSP_FUSED_PROBE", &Options::fused_probe},
 };
 }  // namespace
@@ -447,7 +447,8 @@ int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const d
     int rc;
     const int route = pipeline_route(n, k);
     if (route == 2) {
-        // band route: the pencil stays banded (crawford.hip), the band-16 chase takes the result as it is
+        // band route: the pencil stays banded (crawford.hip: half-width 8 in, half-width 8 out), the one-column chase on tiles of 8
+        // takes the result as it is (BSP_CW_BAND8=0: half-width 15 out, tiles of 16)
         if (!crawford_supported(n, k)) {
             fprintf(stderr, "bspatom: BSP_ROUTE=2 (band route) takes pencils of half-width k - 1 <= 8 and n >= 16 (k = %d, n = %d)\n", k, n);
             return BSP_ERR_UNSUPPORTED;
@@ -458,7 +459,7 @@ int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const d
         if (ev) BSP_HIP(hipEventRecord(ev[1], st));
         if ((rc = crawford_run(n, npad, k, nl, d_SB, d_HB, cw, b.AB, st))) return rc;
         if (ev) BSP_HIP(hipEventRecord(ev[2], st));
-        if ((rc = launch_sb16st(n, npad, nl, b.AB, b.d, b.e, st, b.status, b.sbctl))) return rc;
+        if ((rc = launch_sb16st(n, npad, nl, b.AB, b.d, b.e, st, b.status, b.sbctl, opts().cw_band8 ? 8 : 16))) return rc;
         if (ev) BSP_HIP(hipEventRecord(ev[3], st));
         if (!with_bisect) return BSP_OK;
         if ((rc = launch_bisect(n, npad, nl, b.d, b.e, d_Eout, n, st))) return rc;

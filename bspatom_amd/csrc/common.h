@@ -67,6 +67,9 @@ struct Options {
     int cw_items4 = 1;           // BSP_CW_ITEMS4: 1 = crawford_item4_kernel (four chase items per wave, an item per DPP row in the RQ loop),
                                  // 0 = crawford_item_kernel (one item per wave; the cross-check)
     int cw_nw = 1;               // BSP_CW_NW: waves per workgroup of crawford_item4_kernel (1 or 4; a wave never talks to another)
+    int cw_band8 = 1;            // BSP_CW_BAND8: 1 = the band reduction hands over the band of half-width 8 it really leaves (one 8 x 8 block
+                                 // made triangular at the end) and the chase runs on tiles of 8; 0 = half-width 15, tiles of 16 (as first built)
+    int sb8_wgs = 0;             // BSP_SB8_WGS: workgroups of the tiles-of-8 chase per CU the rings are sized for (0 = what fits: 2)
     int cw_ipw = 0;              // BSP_CW_IPW: items per wave of crawford_item4_kernel (0 = 4; 1, 2: experiment 9; bit-identical results)
     int cw_ldspad = 0;           // BSP_CW_LDSPAD: KB of unused dynamic LDS per workgroup of crawford_item4_kernel (timing experiment: occupancy)
     int cw_onediv = 0;           // BSP_CW_ONEDIV: reflectors of the band route's RQ loop in the one-division form (A/B switch)
@@ -188,7 +191,7 @@ size_t sb2st_ctl_bytes(int batch);
 // two-step route (sbr2.hip): band 64 -> 16 by block bulge chasing, then 16 -> tridiagonal in an LDS window
 int launch_sb2sb(int n, int npad, int batch, double *d_AB, hipStream_t st);
 int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st, int *d_status = nullptr,
-                  void *ctl = nullptr);
+                  void *ctl = nullptr, int hb = 16);
 int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, double *d_e,
                  hipStream_t st, int *d_status = nullptr, void *ctl = nullptr);
 // tridiag.hip

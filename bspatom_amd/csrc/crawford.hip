@@ -566,7 +566,75 @@ __global__ __launch_bounds__(64) void crawford_init_kernel(int n, int k, int N, 
 
 // block tridiagonal (reversed order) -> lower band storage of the band-16 chase in the ORIGINAL order:
 // AB[j * 128 + d] = A(j + d, j), d = 0 .. 31 (zero beyond the half-width 15 and beyond the matrix)
-__global__ void crawford_band_kernel(int n, int npad, int N, const double *__restrict__ Dall, const double *__restrict__ Eall,
+// What the reduction leaves is narrower than block tridiagonal: E_1 .. E_{N-2} are upper triangular -- each is the R of the last RQ
+// factorisation that touched it (item (j, s) leaves E_{p+1} = R, the next item of the sweep fills E_p again and the one after it
+// re-factors that; tools/proto_crawford.py and tests/test_host_cpu.py check it on the dense statement) -- so the matrix has
+// half-width CB except for E_0, which the last item of every sweep leaves full.  One more RQ, E_0 = R Q^T, D_0 <- Q^T D_0 Q (block 0
+// touches nothing else), and the chase that follows works on a band of half-width 8 instead of 15.  One wave per channel: lane
+// i < 8 holds row i of E_0, lane 8 + i row i of D_0.
+__device__ __forceinline__ double cw_rdl(double x, int l)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_readlane(u.i[0], l);
+    r.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+    return r.d;
+}
+__global__ __launch_bounds__(64) void crawford_corner_kernel(int N, double *__restrict__ Dall, double *__restrict__ Eall)
+{
+    const int lane = threadIdx.x, i = lane & 7;
+    const bool isE = lane < 8, isD = lane >= 8 && lane < 16;
+    double *rowp = (isE ? Eall : Dall) + (size_t)blockIdx.x * N * CBB + i * CB;
+    double a[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) a[c] = (isE || isD) ? rowp[c] : 0.0;
+#pragma unroll
+    for (int r = CB - 1; r >= 1; --r) {
+        // the reflector H = I - tau v v^T on columns 0 .. r that leaves row r of E_0 as (0 .. 0, beta, *)
+        double v[CB], nrm2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < CB; ++c) v[c] = c <= r ? cw_rdl(a[c], r) : 0.0;
+#pragma unroll
+        for (int c = 0; c < r; ++c) nrm2 = fma(v[c], v[c], nrm2);
+        if (nrm2 == 0.0) continue;                                         // uniform: the row is in shape already
+        const double alpha = v[r], beta = -copysign(sqrt(fma(alpha, alpha, nrm2)), alpha);
+        const double tau = (beta - alpha) / beta, scale = 1.0 / (alpha - beta);
+#pragma unroll
+        for (int c = 0; c < r; ++c) v[c] *= scale;
+        v[r] = 1.0;
+        // rows of E_0 and of D_0 alike: a <- a H
+        double sdot = 0.0;
+#pragma unroll
+        for (int c = 0; c <= r; ++c) sdot = fma(a[c], v[c], sdot);
+        sdot *= tau;
+#pragma unroll
+        for (int c = 0; c <= r; ++c) a[c] = fma(-sdot, v[c], a[c]);
+        if (isE && i == r) {
+#pragma unroll
+            for (int c = 0; c < r; ++c) a[c] = 0.0;
+            a[r] = beta;
+        }
+        // D_0 <- H (D_0 H): row i -= tau v_i (v^T (D_0 H))
+        double vi = 0.0;
+#pragma unroll
+        for (int c = 0; c <= r; ++c) vi = (i == c) ? v[c] : vi;
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            double y = 0.0;
+#pragma unroll
+            for (int q = 0; q <= r; ++q) y = fma(v[q], cw_rdl(a[c], CB + q), y);
+            if (isD) a[c] = fma(-tau * vi, y, a[c]);
+        }
+    }
+    if (isE || isD) {
+#pragma unroll
+        for (int c = 0; c < CB; ++c) rowp[c] = a[c];
+    }
+}
+
+// hw = half-width handed over: 2 CB - 1 (the block tridiagonal as it stands) or CB (after crawford_corner_kernel; what lies
+// beyond is rounding residue of the RQ factorisations, where LAPACK's own reductions store exact zeros)
+__global__ void crawford_band_kernel(int n, int npad, int N, int hw, const double *__restrict__ Dall, const double *__restrict__ Eall,
                                      double *__restrict__ ABall)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -574,7 +642,7 @@ __global__ void crawford_band_kernel(int n, int npad, int N, const double *__res
     const int j = idx >> 5, d = idx & 31;
     const size_t ch = blockIdx.y;
     double v = 0.0;
-    if (j + d < n && d < 2 * CB) {
+    if (j + d < n && d <= hw) {
         const int ihi = n - 1 - j, ilo = ihi - d;                          // reversed indices, ihi >= ilo
         const int P = ihi >> 3, Pc = ilo >> 3;                             // P - Pc = 2 (d >= 9 only): outside the block tridiagonal
         const double *blk = (P == Pc ? Dall : Eall) + (ch * N + Pc) * CBB;
@@ -650,7 +718,10 @@ int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const doubl
         }
     }
     BSP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(crawford_band_kernel, dim3((npad * 32 + 255) / 256, nl), dim3(256), 0, st, n, npad, N, w.D, w.E, d_AB);
+    const bool band8 = opts().cw_band8 != 0;
+    if (band8) hipLaunchKernelGGL(crawford_corner_kernel, dim3(nl), dim3(64), 0, st, N, w.D, w.E);
+    hipLaunchKernelGGL(crawford_band_kernel, dim3((npad * 32 + 255) / 256, nl), dim3(256), 0, st, n, npad, N, band8 ? CB : 2 * CB - 1,
+                       w.D, w.E, d_AB);
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }

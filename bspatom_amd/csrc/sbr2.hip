@@ -861,160 +861,200 @@ __global__ __launch_bounds__(576) void sb16st_kernel(int n, int npad, int batch,
 // reads (v, tau) of its item from the slot as a broadcast.  (The waves are bound by the latency of their dependent chains, not by
 // issue slots: one wave per SIMD and role; with D and B in one wave the step was 2860 ticks, 2475 of them that wave.)  The first item of a sweep: role 0 forms its reflector from the band
 // column one step ahead (the column is final by then and nobody reads it in between, tools/proto_sbr.py).
+// The kernel is a template on the tile size B: 16 (half-width <= 16: the dense route's second step, and the band route as it first
+// was) and 8 (half-width <= 8: what the band route's reduction really leaves, crawford.hip).  With B = 8 an item is owned by HALF a
+// DPP row, a wave runs EIGHT sweeps and a pass sixteen; a window column has 16 rows; everything else is the same program.
 constexpr int NCW4 = 6, SB16R_THREADS = (NCW4 + 1) * 64;
-constexpr int SB16R_Z = WCOLS * WROWS;                 // z of the diagonal-tile waves [2 groups][4 rows][16]
-constexpr int SB16R_DUMP = SB16R_Z + 128;              // target of masked stores [6 waves][4 rows][16]
-constexpr int SB16R_XS = SB16R_DUMP + 384;             // exchange slots [2 parities][8 sweeps][32]: v (16), tau, padding
-constexpr int SB16R_MODE = SB16R_XS + 512;
-constexpr int SB16R_LDS = (SB16R_MODE + 2) * 8;
+template <int B>
+struct Rw {
+    static constexpr int WR = 2 * B;                   // rows of a window column: the band and what the sweeps leave of their bulges
+    static constexpr int WSH = B == 16 ? 5 : 4;        // log2(WR)
+    static constexpr int RPW = 64 / B;                 // items (sweeps) of a wave
+    static constexpr int NSW = 2 * RPW;                // sweeps of a pass: two groups of RPW
+    static constexpr int MLAG = B == 16 ? 4 : 8;       // steps between the request of a column and the wait for it (about the latency of HBM)
+    static constexpr int LP0 = B * (MLAG + 3);         // columns in the window when a pass starts
+    static constexpr int Z = WCOLS * WR;               // z of the diagonal-tile waves [2 groups][RPW items][B]
+    static constexpr int DUMP = Z + 128;               // target of masked stores [6 waves][RPW items][B]
+    static constexpr int XS = DUMP + 384;              // exchange slots [2 parities][NSW sweeps][2 B]: v (B), tau, padding
+    static constexpr int XPAR = NSW * 2 * B;           // one parity's slots (256 for both B)
+    static constexpr int MODE = XS + 2 * XPAR;
+    static constexpr int LDS = (MODE + 2) * 8;
+    static_assert(B == 16 || B == 8, "tile sizes of the rows kernel");
+    static_assert((1 << WSH) == WR && XPAR == 256 && LP0 + B <= 128, "window layout");
+};
 
-// two row sums at once (the chains interleaved, same operations per value as rsum16)
-__device__ __forceinline__ void rsum16x2(double &a, double &b)
+// Sum over the B lanes that own an item, the total in each of them (B = 8: the first three steps of rsum16)
+template <int B>
+__device__ __forceinline__ double rsumB(double x)
+{
+    x += dppd<0xB1>(x);
+    x += dppd<0x4E>(x);
+    x += dppd<0x141>(x);
+    if (B == 16) x += dppd<0x140>(x);
+    return x;
+}
+// two such sums at once (the chains interleaved, same operations per value)
+template <int B>
+__device__ __forceinline__ void rsumBx2(double &a, double &b)
 {
     a += dppd<0xB1>(a); b += dppd<0xB1>(b);
     a += dppd<0x4E>(a); b += dppd<0x4E>(b);
     a += dppd<0x141>(a); b += dppd<0x141>(b);
-    a += dppd<0x140>(a); b += dppd<0x140>(b);
+    if (B == 16) { a += dppd<0x140>(a); b += dppd<0x140>(b); }
 }
 
-// The reflector of the column whose element j is x0 in lane j of the row: v and tau into the slot xw, beta (lane 0) resp. zeros
+// The reflector of the column whose element j is x0 in lane j of the item: v and tau into the slot xw, beta (lane 0) resp. zeros
 // into the window at index hx (the column's own place).  Branch-free: a column that is zero below its first element gives
 // tau = 0, v = e_0, beta = alpha.
+template <int B>
 __device__ __forceinline__ void next_reflector(double *Lw, const double x0, const int j, const int xw, const int hx)
 {
     double nrm2 = j > 0 ? x0 * x0 : 0.0, alpha = j == 0 ? x0 : 0.0;
-    rsum16x2(nrm2, alpha);
+    rsumBx2<B>(nrm2, alpha);
     const bool nz = nrm2 != 0.0;
     const double beta0 = -copysign(sqrt(fma(alpha, alpha, nz ? nrm2 : 1.0)), alpha);      // never zero
     const double tq0 = (beta0 - alpha) / beta0, scale0 = 1.0 / (alpha - beta0);
     const double beta = nz ? beta0 : alpha, tq = nz ? tq0 : 0.0, scale = nz ? scale0 : 0.0;
     Lw[xw + j] = j == 0 ? 1.0 : x0 * scale;
-    if (j == 0) Lw[xw + 16] = tq;
+    if (j == 0) Lw[xw + B] = tq;
     Lw[hx] = j == 0 ? beta : 0.0;
 }
 
-// Window index of the element (r0 + 16 + j, r0 + i) of an item's next tile, i = 0 .. 15, as base[i] + 31 i: the column r0 + i wraps
-// around the ring from i = 512 - (r0 mod 512) on
-template <bool FAST>                                                   // FAST: no tile of the wave wraps
-__device__ __forceinline__ void next_tile_addr(const int r0, const int j, int (&at)[16])
+// Window index of the element (r0 + B + j, r0 + i) of an item's next tile, i = 0 .. B - 1, as base[i] + (WR - 1) i: the column
+// r0 + i wraps around the ring from i = 512 - (r0 mod 512) on
+template <int B, bool FAST>                                            // FAST: no tile of the wave wraps
+__device__ __forceinline__ void next_tile_addr(const int r0, const int j, int (&at)[B])
 {
-    const int cb = r0 & (WCOLS - 1), a0 = (cb << 5) + 16 + j, iw = WCOLS - cb;
+    const int cb = r0 & (WCOLS - 1), a0 = (cb << Rw<B>::WSH) + B + j, iw = WCOLS - cb;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) at[i] = (FAST || i < iw) ? a0 : a0 - WCOLS * WROWS;
+    for (int i = 0; i < B; ++i) at[i] = (FAST || i < iw) ? a0 : a0 - WCOLS * Rw<B>::WR;
 }
-// ... of the element D(i, j) of its diagonal tile, from the stored triangle: column r0 + min(i, j) (wraps when both do), 31 min + max
-template <bool FAST>
-__device__ __forceinline__ void diag_tile_addr(const int r0, const int j, const int (&offD)[16], int (&ad)[16])
+// ... of the element D(i, j) of its diagonal tile, from the stored triangle: column r0 + min(i, j) (wraps when both do),
+// (WR - 1) min + max
+template <int B, bool FAST>
+__device__ __forceinline__ void diag_tile_addr(const int r0, const int j, const int (&offD)[B], int (&ad)[B])
 {
-    const int cb = r0 & (WCOLS - 1), ud = cb << 5, iw = WCOLS - cb, udq = j >= iw ? ud - WCOLS * WROWS : ud;
+    const int cb = r0 & (WCOLS - 1), ud = cb << Rw<B>::WSH, iw = WCOLS - cb, udq = j >= iw ? ud - WCOLS * Rw<B>::WR : ud;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) ad[i] = ((!FAST && i >= iw) ? udq : ud) + offD[i];
+    for (int i = 0; i < B; ++i) ad[i] = ((!FAST && i >= iw) ? udq : ud) + offD[i];
 }
 
 // role 0, the arithmetic of an item: next tile bt (lane j = row j) <- bt H, the reflector of its first column for the next item
-__device__ __forceinline__ void chase4_next(double *Lw, double (&bt)[16], const double (&v)[16], const double tq, const int (&at)[16],
+template <int B>
+__device__ __forceinline__ void chase4_next(double *Lw, double (&bt)[B], const double (&v)[B], const double tq, const int (&at)[B],
                                             const int j, const int xw)
 {
     double y0 = bt[0], y1 = v[1] * bt[1], y2 = v[2] * bt[2], y3 = v[3] * bt[3];
 #pragma unroll
-    for (int i = 4; i < 16; i += 4) {
+    for (int i = 4; i < B; i += 4) {
         y0 = fma(v[i], bt[i], y0); y1 = fma(v[i + 1], bt[i + 1], y1);
         y2 = fma(v[i + 2], bt[i + 2], y2); y3 = fma(v[i + 3], bt[i + 3], y3);
     }
     const double ct = tq * ((y0 + y1) + (y2 + y3));
-    next_reflector(Lw, bt[0] - ct, j, xw, at[0]);                    // B'(j, 0): element j of the next item's column
+    next_reflector<B>(Lw, bt[0] - ct, j, xw, at[0]);                 // B'(j, 0): element j of the next item's column
 #pragma unroll
-    for (int i = 1; i < 16; ++i) Lw[at[i] + 31 * i] = fma(-ct, v[i], bt[i]);
+    for (int i = 1; i < B; ++i) Lw[at[i] + (Rw<B>::WR - 1) * i] = fma(-ct, v[i], bt[i]);
 }
 
 // role 1: diagonal tile d (lane j = column j) <- H d H; (v, tau) from slot xr
-__device__ __forceinline__ void chase4_diag(double *Lw, const double (&d)[16], const int (&ad)[16], const int j, const int xr,
+template <int B>
+__device__ __forceinline__ void chase4_diag(double *Lw, const double (&d)[B], const int (&ad)[B], const int j, const int xr,
                                             const int zi, const int dumpi)
 {
-    double v[16];
+    double v[B];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = Lw[xr + i];
-    const double tq = Lw[xr + 16], vl = Lw[xr + j];
+    for (int i = 0; i < B; ++i) v[i] = Lw[xr + i];
+    const double tq = Lw[xr + B], vl = Lw[xr + j];
     double y0 = d[0], y1 = v[1] * d[1], y2 = v[2] * d[2], y3 = v[3] * d[3];
 #pragma unroll
-    for (int i = 4; i < 16; i += 4) {
+    for (int i = 4; i < B; i += 4) {
         y0 = fma(v[i], d[i], y0); y1 = fma(v[i + 1], d[i + 1], y1);
         y2 = fma(v[i + 2], d[i + 2], y2); y3 = fma(v[i + 3], d[i + 3], y3);
     }
     const double p = tq * ((y0 + y1) + (y2 + y3));
-    const double vtp = rsum16(vl * p);
+    const double vtp = rsumB<B>(vl * p);
     const double z = fma(-(0.5 * tq * vtp), vl, p);
     Lw[zi + j] = z;
-    double zz[16];
+    double zz[B];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) zz[i] = Lw[zi + i];
+    for (int i = 0; i < B; ++i) zz[i] = Lw[zi + i];
     // the lower triangle is what the band stores; the mirrored values go to the dump (a select on the address, no branch)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) Lw[i >= j ? ad[i] : dumpi + i] = fma(-zz[i], vl, fma(-v[i], z, d[i]));
+    for (int i = 0; i < B; ++i) Lw[i >= j ? ad[i] : dumpi + i] = fma(-zz[i], vl, fma(-v[i], z, d[i]));
 }
 
-// role 2: bulge tile of item (r0, c0): column c0 + j, rows r0 .. r0 + 15 (contiguous; no wrap inside a lane).  Column 0 holds
+// role 2: bulge tile of item (r0, c0): column c0 + j, rows r0 .. r0 + B - 1 (contiguous; no wrap inside a lane).  Column 0 holds
 // (beta, 0, .., 0) already: lane 0 works on the dump
+template <int B>
 __device__ __forceinline__ void chase4_bulge(double *Lw, const int r0, const int c0, const int j, const int xr, const int dumpi)
 {
-    double v[16], b[16];
+    double v[B], b[B];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = Lw[xr + i];
-    const double tq = Lw[xr + 16];
-    int ab = (((c0 + j) & (WCOLS - 1)) << 5) + (r0 - c0 - j);
+    for (int i = 0; i < B; ++i) v[i] = Lw[xr + i];
+    const double tq = Lw[xr + B];
+    int ab = (((c0 + j) & (WCOLS - 1)) << Rw<B>::WSH) + (r0 - c0 - j);
     if (j == 0) ab = dumpi;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) b[i] = Lw[ab + i];
+    for (int i = 0; i < B; ++i) b[i] = Lw[ab + i];
     double w0 = b[0], w1 = v[1] * b[1], w2 = v[2] * b[2], w3 = v[3] * b[3];
 #pragma unroll
-    for (int i = 4; i < 16; i += 4) {
+    for (int i = 4; i < B; i += 4) {
         w0 = fma(v[i], b[i], w0); w1 = fma(v[i + 1], b[i + 1], w1);
         w2 = fma(v[i + 2], b[i + 2], w2); w3 = fma(v[i + 3], b[i + 3], w3);
     }
     const double cb = tq * ((w0 + w1) + (w2 + w3));
 #pragma unroll
-    for (int i = 0; i < 16; ++i) Lw[ab + i] = fma(-cb, v[i], b[i]);
+    for (int i = 0; i < B; ++i) Lw[ab + i] = fma(-cb, v[i], b[i]);
 }
 
-// Rows and columns of the band storage beyond the matrix are made zero before sb16r_kernel runs, column npad (the first of
-// the slack behind the band, ab_stride) included: the kernel's data-moving wave copies whole columns into LDS without looking
-// at them, and takes column npad for every column further right.
-__global__ void band_tail_zero_kernel(int n, int npad, double *__restrict__ ABall)
+// Rows and columns of the band storage beyond the matrix are made zero before the rows kernel runs (wr = the rows of its window
+// column), column npad (the first of the slack behind the band, ab_stride) included: the kernel's data-moving wave copies whole
+// columns into LDS without looking at them, and takes column npad for every column further right.
+__global__ void band_tail_zero_kernel(int n, int npad, int wr, double *__restrict__ ABall)
 {
     double *AB = ABall + (size_t)blockIdx.x * ab_stride(npad);
-    const int c_lo = n - (WROWS - 1) > 0 ? n - (WROWS - 1) : 0;
-    for (int idx = threadIdx.x; idx < (npad + 1 - c_lo) * WROWS; idx += blockDim.x) {
-        const int c = c_lo + (idx >> 5), d = idx & 31;
+    const int c_lo = n - (wr - 1) > 0 ? n - (wr - 1) : 0;
+    for (int idx = threadIdx.x; idx < (npad + 1 - c_lo) * wr; idx += blockDim.x) {
+        const int c = c_lo + idx / wr, d = idx % wr;
         if (c + d >= n) AB[(size_t)c * LD + d] = 0.0;
     }
 }
 
-// One step of the data-moving wave.  Sixteen columns enter the window per step by LDS-DMA (four instructions of 1 KB: a column
-// of the window is the first 32 rows of the band column, 256 bytes here and there; no registers, so no wait the compiler could
-// place -- with register staging it made every step wait for the loads of the step before, HBM latency, and the data-moving wave
-// was the longest of the step); they have landed four steps later (the wait at the end of the step, a literal count: the counter
-// is in order over loads and stores and a step issues 4 + 8 of them, 13 with the poll) and are first touched six steps later.
-// Columns leave the window with plain stores, at most 16 per step.
-template <int PH>
+// One step of the data-moving wave.  B columns enter the window per step by LDS-DMA (B = 16: four instructions of 1 KB, a column
+// of the window is the first 32 rows of the band column, 256 bytes here and there; B = 8: one instruction, 128 bytes of each of 8
+// columns; no registers, so no wait the compiler could place -- with register staging it made every step wait for the loads of
+// the step before, HBM latency, and the data-moving wave was the longest of the step); they have landed MLAG steps later (the wait
+// at the end of the step, a literal count: the counter is in order over loads and stores and a step issues 4 + 8 resp. 1 + 2 of
+// them, one more with the poll) and are first touched two steps after that.  Columns leave the window with plain stores, at most
+// B per step.
+template <int B, int PH>
 __device__ __forceinline__ void mover_step(double *Lw, double *__restrict__ AB, const int n, const int npad, const int LP,
                                            const int RP, const int RPn, const int RPold, const int ps, const int lane,
                                            const unsigned long long *pollp, unsigned long long *pubp, unsigned long long &pw,
                                            unsigned long long &ptmp, Sb16Ctl *C, int *status, const bool diag, long long (&dacc)[5])
 {
+    constexpr int WSH = Rw<B>::WSH;
     long long ts = diag ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #define MV_STAMP(q) if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[q] += t_ - ts; ts = t_; }
-    const int md = lane & 31, mh = lane >> 5;                       // column-out lane: row md of columns 2 i + mh
-    if (PH == 0 && pollp && ps > 0 && LP < n) {                    // the 64 columns requested in these four steps, as the pass before left them
-        const int need = LP + 64 < n ? LP + 64 : n;
+    if (PH == 0 && pollp && ps > 0 && LP < n) {                    // the 4 B columns requested in these four steps, as the pass before left them
+        const int need = LP + 4 * B < n ? LP + 4 * B : n;
         const unsigned long long want = ((unsigned long long)(ps - 1) << 32) + (unsigned)need;
         if (pw < want) s16_wait(pollp, want, C, status);            // pw was requested three steps ago
         else asm volatile("buffer_inv sc1" ::: "memory");
     }
+    if (B == 16) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {                                   // columns LP + 4 q .. + 3: lane = (column lane >> 4, rows 2 (lane & 15), + 1)
-        const int c = LP + 4 * q, cl = c + (lane >> 4);
-        const double *src = AB + (size_t)(cl < npad ? cl : npad) * LD + 2 * (lane & 15);
-        double *dst = Lw + ((c & (WCOLS - 1)) << 5);
+        for (int q = 0; q < 4; ++q) {                               // columns LP + 4 q .. + 3: lane = (column lane >> 4, rows 2 (lane & 15), + 1)
+            const int c = LP + 4 * q, cl = c + (lane >> 4);
+            const double *src = AB + (size_t)(cl < npad ? cl : npad) * LD + 2 * (lane & 15);
+            double *dst = Lw + ((c & (WCOLS - 1)) << WSH);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+    } else {                                                        // columns LP .. LP + 7: lane = (column lane >> 3, rows 2 (lane & 7), + 1)
+        const int cl = LP + (lane >> 3);
+        const double *src = AB + (size_t)(cl < npad ? cl : npad) * LD + 2 * (lane & 7);
+        double *dst = Lw + ((LP & (WCOLS - 1)) << WSH);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     }
@@ -1024,20 +1064,23 @@ __device__ __forceinline__ void mover_step(double *Lw, double *__restrict__ AB, 
     if (PH == 1 && pollp) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "+v"(ptmp) : "v"(pollp) : "memory");
     MV_STAMP(1)                                                     // poll check and requests
     {
+        // column-out lane: row md of the columns RP + mh, RP + mh + 64 / WR, ...
+        const int md = lane & (Rw<B>::WR - 1), mh = lane >> WSH;
         const unsigned c0_ = (unsigned)(RP + mh), dumpo = (unsigned)npad * LD + 64 + lane;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const unsigned c = c0_ + 2 * i;
+        for (int i = 0; i < B * Rw<B>::WR / 64; ++i) {
+            const unsigned c = c0_ + (64 / Rw<B>::WR) * i;
             const unsigned o = c < (unsigned)RPn ? c * LD + md : dumpo;
-            AB[o] = Lw[((c & (WCOLS - 1)) << 5) + md];
+            AB[o] = Lw[((c & (WCOLS - 1)) << WSH) + md];
         }
     }
     MV_STAMP(0)                                                     // columns out: LDS reads, stores issued
-    // All but the 48 youngest operations complete: the columns requested FOUR steps ago are in the window, and the stores of
-    // that step have reached the L2 -- the columns left of RPold, progress for the member that runs the next pass.  (Two steps
-    // were not enough: a step is shorter than half the latency of HBM and the wave waited for it every time.)
-    asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-    MV_STAMP(2)                                                     // the wait for the operations of four steps ago
+    // All but the operations of the last MLAG steps complete: the columns requested MLAG steps ago are in the window, and the
+    // stores of that step have reached the L2 -- the columns left of RPold, progress for the member that runs the next pass.  (Two
+    // steps were not enough at B = 16: a step is shorter than half the latency of HBM and the wave waited for it every time.)
+    if (B == 16) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    MV_STAMP(2)                                                     // the wait for the operations of MLAG steps ago
 #undef MV_STAMP
     if (PH == 3 && pubp && lane == 0)
         __hip_atomic_store(pubp, ((unsigned long long)ps << 32) + (unsigned)RPold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1047,19 +1090,32 @@ __device__ __forceinline__ void mover_step(double *Lw, double *__restrict__ AB, 
     }
 }
 
-__global__ __launch_bounds__(SB16R_THREADS) void sb16r_kernel(int n, int npad, int batch, double *__restrict__ ABall,
-                                                              double *__restrict__ dall, double *__restrict__ eall,
-                                                              long long *diag, Sb16Ctl *ctl, int P, int *status, int force_abort)
+// barrier of a chasing wave whose loads for the next step may still be in flight; its stores may not (LDS operations of a wave
+// complete in order: with more than 15 (B = 16) resp. 7 (B = 8) load instructions behind the last store -- 16 / 24 resp. 8 / 12 in
+// the code as compiled -- that many outstanding means the stores are done)
+template <int B>
+__device__ __forceinline__ void stores_done_barrier()
 {
+    if (B == 16) asm volatile("s_waitcnt lgkmcnt(15)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(7)\n\ts_barrier" ::: "memory");
+}
+
+template <int B>
+__global__ __launch_bounds__(SB16R_THREADS) void sbr_rows_kernel(int n, int npad, int batch, double *__restrict__ ABall,
+                                                                 double *__restrict__ dall, double *__restrict__ eall,
+                                                                 long long *diag, Sb16Ctl *ctl, int P, int *status, int force_abort)
+{
+    using W = Rw<B>;
+    constexpr int WSH = W::WSH, WR = W::WR, RPW = W::RPW, NSW = W::NSW, MLAG = W::MLAG, LP0 = W::LP0;
     extern __shared__ double lds[];
     double *Lw = lds;
     long long dacc[5] = {0, 0, 0, 0, 0}, dt0 = 0;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 15, g = lane >> 4;
-    // chasing waves: 0, 1 = roles 0, 1 of sweeps 0..3; 2, 3 = roles 0, 1 of sweeps 4..7; 4, 5 = role 2 of sweeps 0..3, 4..7 (the waves with
-    // the long chains first, so that each has a SIMD where it is the only long one)
-    const int grp = wv < 4 ? (wv >> 1) & 1 : wv & 1, role = wv < 4 ? wv & 1 : 2, sw = 4 * grp + g;
-    const int zi = SB16R_Z + 64 * grp + 16 * g, dumpi = SB16R_DUMP + 64 * (wv % NCW4) + 16 * g;
+    const int j = lane & (B - 1), g = lane / B;
+    // chasing waves: 0, 1 = roles 0, 1 of the first group of sweeps; 2, 3 = roles 0, 1 of the second; 4, 5 = role 2 of the two groups (the
+    // waves with the long chains first, so that each has a SIMD where it is the only long one)
+    const int grp = wv < 4 ? (wv >> 1) & 1 : wv & 1, role = wv < 4 ? wv & 1 : 2, sw = RPW * grp + g;
+    const int zi = W::Z + 64 * grp + B * g, dumpi = W::DUMP + 64 * (wv % NCW4) + B * g;
     // ---- which channel; alone (ctl == nullptr) or member w of a ring of P workgroups
     int chn = blockIdx.x, w = 0, stride = 1;
     const unsigned long long *pollp = nullptr;
@@ -1070,7 +1126,7 @@ __global__ __launch_bounds__(SB16R_THREADS) void sb16r_kernel(int n, int npad, i
         chn = grp * 8 + (rr & 7); w = rr >> 3;
         if (chn >= batch) return;
         C = ctl + chn;
-        int *modep = reinterpret_cast<int *>(lds + SB16R_MODE);
+        int *modep = reinterpret_cast<int *>(lds + W::MODE);
         if (tid == 0) {
             const unsigned long long xcc = (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu);   // HW_REG_XCC_ID
             const unsigned long long mine = (0x10ull | xcc) << (8 * w);
@@ -1102,43 +1158,43 @@ __global__ __launch_bounds__(SB16R_THREADS) void sb16r_kernel(int n, int npad, i
         else w = 0;
     }
     double *AB = ABall + (size_t)chn * ab_stride(npad);
-    const int npass = (n - 2 + NW2 - 1) / NW2;
+    const int npass = (n - 2 + NSW - 1) / NSW;
     for (int ps = w; ps < npass; ps += stride) {
-        const int s0 = ps * NW2;
-        int RP = s0, LP = s0 + 112;                       // columns leave the window left of RP; LP is the next one to be requested
-        if (pollp && ps > 0) {                            // the first 128 columns of this pass, as the pass before left them
+        const int s0 = ps * NSW;
+        int RP = s0, LP = s0 + LP0;                       // columns leave the window left of RP; LP is the next one to be requested
+        if (pollp && ps > 0) {                            // the first LP0 + B columns of this pass, as the pass before left them
             if (tid == 0) {
-                const int need = s0 + 128 < n ? s0 + 128 : n;
+                const int need = s0 + LP0 + B < n ? s0 + LP0 + B : n;
                 s16_wait(pollp, ((unsigned long long)(ps - 1) << 32) + (unsigned)need, C, status);
             }
             __syncthreads();
             asm volatile("buffer_inv sc1" ::: "memory");
         }
-        for (int idx = tid; idx < 112 * WROWS; idx += SB16R_THREADS) {
-            const int c = s0 + (idx >> 5), d = idx & 31;
-            Lw[((c & (WCOLS - 1)) << 5) + d] = c + d < n ? AB[(size_t)c * LD + d] : 0.0;
+        for (int idx = tid; idx < LP0 * WR; idx += SB16R_THREADS) {
+            const int c = s0 + (idx >> WSH), d = idx & (WR - 1);
+            Lw[((c & (WCOLS - 1)) << WSH) + d] = c + d < n ? AB[(size_t)c * LD + d] : 0.0;
         }
         __syncthreads();
         // the reflector of the pass's first item (sweep s0, k = 0) into its slot of step 0
         if (wv == 0 && g == 0) {
-            const int hx = ((s0 & (WCOLS - 1)) << 5) + 1 + j;
-            next_reflector(Lw, Lw[hx], j, SB16R_XS, hx);
+            const int hx = ((s0 & (WCOLS - 1)) << WSH) + 1 + j;
+            next_reflector<B>(Lw, Lw[hx], j, W::XS, hx);
         }
-        const int nsteps = (n - s0 - 1 + B2 - 1) / B2 + LAG * (NW2 - 1);
+        const int nsteps = (n - s0 - 1 + B - 1) / B + LAG * (NSW - 1);
 #define SB16R_RPN(t) \
-        int RPn = s0 + NW2 + B2 * ((t) - LAG * (NW2 - 1) - 1);   /* columns leaving: left of the trailing sweep's tiles */ \
+        int RPn = s0 + NSW + B * ((t) - LAG * (NSW - 1) - 1);   /* columns leaving: left of the trailing sweep's tiles */ \
         if (RPn > n) RPn = n; \
         if (RPn < RP) RPn = RP;
         if (wv == NCW4) {                                 // the last wave moves data and does nothing else
             unsigned long long pw = 0, ptmp = 0;          // the partner's progress word as last seen / as last requested
-            int RPold = RP;                               // RP one step ago
+            int RPold = RP;                               // RP MLAG steps ago
             __syncthreads();
 #define SB16R_MSTEP(PH) \
             if (t + PH < nsteps) { \
                 SB16R_RPN(t + PH) \
-                { int r4 = s0 + NW2 + B2 * ((t + PH - 4) - LAG * (NW2 - 1) - 1);      /* RPn of four steps ago */ \
+                { int r4 = s0 + NSW + B * ((t + PH - MLAG) - LAG * (NSW - 1) - 1);      /* RPn of MLAG steps ago */ \
                   RPold = r4 > n ? n : (r4 < s0 ? s0 : r4); } \
-                mover_step<PH>(Lw, AB, n, npad, LP + 16 * PH, RP, RPn, RPold, ps, lane, pollp, pubp, pw, ptmp, C, status, diag != nullptr, dacc); \
+                mover_step<B, PH>(Lw, AB, n, npad, LP + B * PH, RP, RPn, RPold, ps, lane, pollp, pubp, pw, ptmp, C, status, diag != nullptr, dacc); \
                 if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime(); \
                 RP = RPn; \
                 lds_only_barrier(); \
@@ -1146,11 +1202,11 @@ __global__ __launch_bounds__(SB16R_THREADS) void sb16r_kernel(int n, int npad, i
             }
             for (int t = 0; t < nsteps; t += 4) {
                 SB16R_MSTEP(0) SB16R_MSTEP(1) SB16R_MSTEP(2) SB16R_MSTEP(3)
-                LP += 64;
+                LP += 4 * B;
             }
 #undef SB16R_MSTEP
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            LP = s0 + 112;
+            LP = s0 + LP0;
         } else {
             // Roles 0 and 1 fetch the tile of their NEXT item at the end of a step, behind their stores: both tiles are final by
             // then (the lag of three leaves the diagonal tile of item k + 1 untouched from the step before item k runs, tools/proto_sbr.py;
@@ -1160,76 +1216,74 @@ __global__ __launch_bounds__(SB16R_THREADS) void sb16r_kernel(int n, int npad, i
             // operations are in order): its chain starts with the dot products.
             const int s4 = s0 + sw;
             const bool live = s4 < n - 2;
-            const int xs0 = SB16R_XS + (sw << 5);
+            const int xs0 = W::XS + sw * 2 * B;
             if (role == 0) {
-                double bt[16], v[16], tq = 0.0;
-                int at[16];
-                for (int i = 0; i < 16; ++i) { bt[i] = 0.0; v[i] = 0.0; at[i] = 0; }
+                double bt[B], v[B], tq = 0.0;
+                int at[B];
+                for (int i = 0; i < B; ++i) { bt[i] = 0.0; v[i] = 0.0; at[i] = 0; }
                 if (sw == 0 && live && s4 + 1 < n) {      // item (s0, 0) runs at step 0
-                    next_tile_addr<false>(s4 + 1, j, at);
+                    next_tile_addr<B, false>(s4 + 1, j, at);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) { bt[i] = Lw[at[i] + 31 * i]; v[i] = Lw[xs0 + i]; }
-                    tq = Lw[xs0 + 16];
+                    for (int i = 0; i < B; ++i) { bt[i] = Lw[at[i] + (WR - 1) * i]; v[i] = Lw[xs0 + i]; }
+                    tq = Lw[xs0 + B];
                 }
                 __syncthreads();
                 for (int t = 0; t < nsteps; ++t) {
                     SB16R_RPN(t)
                     RP = RPn;
                     if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime();
-                    const int k4 = t - LAG * sw, r04 = s4 + 1 + B2 * k4;   // row g of the wave: sweep s0 + sw, item t - 3 sw
-                    const bool act = k4 >= 0 && live && r04 < n, actN = k4 >= -1 && live && r04 + B2 < n;
+                    const int k4 = t - LAG * sw, r04 = s4 + 1 + B * k4;   // item g of the wave: sweep s0 + sw, item t - 3 sw
+                    const bool act = k4 >= 0 && live && r04 < n, actN = k4 >= -1 && live && r04 + B < n;
                     const int xw = xs0 + (((t + 1) & 1) << 8);
                     if (act) {
-                        chase4_next(Lw, bt, v, tq, at, j, xw);
+                        chase4_next<B>(Lw, bt, v, tq, at, j, xw);
                     } else if (k4 == -1 && live) {        // the sweep starts in the next step: its reflector from the band column
-                        const int hx = ((s4 & (WCOLS - 1)) << 5) + 1 + j;
-                        next_reflector(Lw, Lw[hx], j, xw, hx);
+                        const int hx = ((s4 & (WCOLS - 1)) << WSH) + 1 + j;
+                        next_reflector<B>(Lw, Lw[hx], j, xw, hx);
                     }
                     // for the next step: (v, tau) back from the slot, the next item's tile (general addresses for the whole wave
-                    // if the tile of one of its rows wraps around the ring: one step in eight)
-                    const bool wrapN = __builtin_amdgcn_ballot_w64(actN && ((r04 + B2) & (WCOLS - 1)) > WCOLS - 16) != 0;
+                    // if the tile of one of its items wraps around the ring)
+                    const bool wrapN = __builtin_amdgcn_ballot_w64(actN && ((r04 + B) & (WCOLS - 1)) > WCOLS - B) != 0;
                     if (actN) {
-                        if (wrapN) next_tile_addr<false>(r04 + B2, j, at);
-                        else next_tile_addr<true>(r04 + B2, j, at);
+                        if (wrapN) next_tile_addr<B, false>(r04 + B, j, at);
+                        else next_tile_addr<B, true>(r04 + B, j, at);
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) v[i] = Lw[xw + i];
-                        tq = Lw[xw + 16];
+                        for (int i = 0; i < B; ++i) v[i] = Lw[xw + i];
+                        tq = Lw[xw + B];
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) bt[i] = Lw[at[i] + 31 * i];
+                        for (int i = 0; i < B; ++i) bt[i] = Lw[at[i] + (WR - 1) * i];
                     }
                     if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[2] += t_ - dt0; dt0 = t_; }
-                    // the loads above may still be in flight at the barrier; the stores before them may not (LDS operations of a
-                    // wave complete in order: with more than 15 loads behind the last store, 15 outstanding means the stores are done)
-                    if (__builtin_amdgcn_ballot_w64(actN) != 0) asm volatile("s_waitcnt lgkmcnt(15)\n\ts_barrier" ::: "memory");
+                    if (__builtin_amdgcn_ballot_w64(actN) != 0) stores_done_barrier<B>();
                     else lds_only_barrier();
                     if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; }
                 }
             } else if (role == 1) {
-                double d[16];
-                int ad[16], offD[16];
-                for (int i = 0; i < 16; ++i) { d[i] = 0.0; ad[i] = 0; offD[i] = i >= j ? 31 * j + i : 31 * i + j; }
+                double d[B];
+                int ad[B], offD[B];
+                for (int i = 0; i < B; ++i) { d[i] = 0.0; ad[i] = 0; offD[i] = i >= j ? (WR - 1) * j + i : (WR - 1) * i + j; }
                 if (sw == 0 && live && s4 + 1 < n) {
-                    diag_tile_addr<false>(s4 + 1, j, offD, ad);
+                    diag_tile_addr<B, false>(s4 + 1, j, offD, ad);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) d[i] = Lw[ad[i]];
+                    for (int i = 0; i < B; ++i) d[i] = Lw[ad[i]];
                 }
                 __syncthreads();
                 for (int t = 0; t < nsteps; ++t) {
                     SB16R_RPN(t)
                     RP = RPn;
                     if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime();
-                    const int k4 = t - LAG * sw, r04 = s4 + 1 + B2 * k4;
-                    const bool act = k4 >= 0 && live && r04 < n, actN = k4 >= -1 && live && r04 + B2 < n;
-                    if (act) chase4_diag(Lw, d, ad, j, xs0 + ((t & 1) << 8), zi, dumpi);
-                    const bool wrapN = __builtin_amdgcn_ballot_w64(actN && ((r04 + B2) & (WCOLS - 1)) > WCOLS - 16) != 0;
+                    const int k4 = t - LAG * sw, r04 = s4 + 1 + B * k4;
+                    const bool act = k4 >= 0 && live && r04 < n, actN = k4 >= -1 && live && r04 + B < n;
+                    if (act) chase4_diag<B>(Lw, d, ad, j, xs0 + ((t & 1) << 8), zi, dumpi);
+                    const bool wrapN = __builtin_amdgcn_ballot_w64(actN && ((r04 + B) & (WCOLS - 1)) > WCOLS - B) != 0;
                     if (actN) {
-                        if (wrapN) diag_tile_addr<false>(r04 + B2, j, offD, ad);
-                        else diag_tile_addr<true>(r04 + B2, j, offD, ad);
+                        if (wrapN) diag_tile_addr<B, false>(r04 + B, j, offD, ad);
+                        else diag_tile_addr<B, true>(r04 + B, j, offD, ad);
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) d[i] = Lw[ad[i]];
+                        for (int i = 0; i < B; ++i) d[i] = Lw[ad[i]];
                     }
                     if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[2] += t_ - dt0; dt0 = t_; }
-                    if (__builtin_amdgcn_ballot_w64(actN) != 0) asm volatile("s_waitcnt lgkmcnt(15)\n\ts_barrier" ::: "memory");
+                    if (__builtin_amdgcn_ballot_w64(actN) != 0) stores_done_barrier<B>();
                     else lds_only_barrier();
                     if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; }
                 }
@@ -1239,8 +1293,8 @@ __global__ __launch_bounds__(SB16R_THREADS) void sb16r_kernel(int n, int npad, i
                     SB16R_RPN(t)
                     RP = RPn;
                     if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime();
-                    const int k4 = t - LAG * sw, r04 = s4 + 1 + B2 * k4;
-                    if (k4 > 0 && live && r04 < n) chase4_bulge(Lw, r04, r04 - B2, j, xs0 + ((t & 1) << 8), dumpi);
+                    const int k4 = t - LAG * sw, r04 = s4 + 1 + B * k4;
+                    if (k4 > 0 && live && r04 < n) chase4_bulge<B>(Lw, r04, r04 - B, j, xs0 + ((t & 1) << 8), dumpi);
                     if (diag) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[2] += t_ - dt0; dt0 = t_; }
                     lds_only_barrier();
                     if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; }
@@ -1248,12 +1302,12 @@ __global__ __launch_bounds__(SB16R_THREADS) void sb16r_kernel(int n, int npad, i
             }
         }
 #undef SB16R_RPN
-        LP += 64 * ((nsteps + 3) / 4);                    // what was requested (far beyond n by the end of a pass)
+        LP += 4 * B * ((nsteps + 3) / 4);                 // what was requested (far beyond n by the end of a pass)
         __syncthreads();
         int hi = LP < n ? LP : n;
-        for (int idx = tid; idx < (hi - RP) * WROWS; idx += SB16R_THREADS) {
-            const int c = RP + (idx >> 5), d = idx & 31;
-            AB[(size_t)c * LD + d] = Lw[((c & (WCOLS - 1)) << 5) + d];
+        for (int idx = tid; idx < (hi - RP) * WR; idx += SB16R_THREADS) {
+            const int c = RP + (idx >> WSH), d = idx & (WR - 1);
+            AB[(size_t)c * LD + d] = Lw[((c & (WCOLS - 1)) << WSH) + d];
         }
         __syncthreads();
         if (pubp && tid == 0)
@@ -1310,20 +1364,48 @@ int launch_sb2sb(int n, int npad, int batch, double *d_AB, hipStream_t st)
     return BSP_OK;
 }
 
-int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st, int *d_status, void *ctl)
+// hb = 16: band of half-width <= 16 (the dense route's second step); hb = 8: half-width <= 8 (the band route, crawford.hip), rows
+// kernel with tiles of 8 only
+int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double *d_e, hipStream_t st, int *d_status, void *ctl, int hb)
 {
     static bool attr = false;
+    static int wg8 = 1;                                     // workgroups of the B = 8 kernel a CU holds (LDS: 2; registers permitting)
     if (!attr) {
         BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sb16st_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     SB16_LDS));
-        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sb16r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    SB16R_LDS));
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sbr_rows_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    Rw<16>::LDS));
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sbr_rows_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    Rw<8>::LDS));
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(sbr_rows_kernel<8>), SB16R_THREADS,
+                                                         Rw<8>::LDS) == hipSuccess && nb >= 1) wg8 = nb > 2 ? 2 : nb;
         attr = true;
     }
-    // workgroups per channel: as many as the chip has CUs for (each needs a whole CU's LDS), at most 8
-    int P = opts().sb2st_ring > 0 ? opts().sb2st_ring : (batch > 128 ? 1 : (batch > 64 ? 2 : (batch > 32 ? 4 : 8)));
+    if (hb != 16 && hb != 8) return BSP_ERR_ARG;
+    const bool rows = hb == 8 || opts().sb16_rows != 0;
+    const int nsw = hb == 8 ? Rw<8>::NSW : NW2;            // sweeps of a pass
+    // workgroups per channel: as many as the chip has room for (B = 16: each needs a whole CU's LDS), at most 8
+    int P;
+    if (opts().sb2st_ring > 0) P = opts().sb2st_ring;
+    else if (hb == 16) P = batch > 128 ? 1 : (batch > 64 ? 2 : (batch > 32 ? 4 : 8));
+    else {
+        int cus = 256;
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        // one workgroup per CU while that gives a channel four members, two per CU (what the LDS holds) beyond: measured at 128 /
+        // 64 channels, chase in ms: four members on one CU each - / 17.7, two per CU 26.1 / 18.9 (eight members), two members 30.8 / -
+        const int wgs = opts().sb8_wgs > 0 && opts().sb8_wgs < wg8 ? opts().sb8_wgs : wg8;
+        for (P = 8; P > 1 && ((batch + 7) / 8) * 8 * P > cus; P /= 2) {}
+        if (P < 4 && opts().sb8_wgs == 0)
+            for (P = 4; P > 1 && ((batch + 7) / 8) * 8 * P > cus * wgs; P /= 2) {}
+        else if (opts().sb8_wgs > 0)
+            for (P = 8; P > 1 && ((batch + 7) / 8) * 8 * P > cus * wgs; P /= 2) {}
+    }
     if (P > 8) P = 8;
-    while (P > 1 && (n - 2) / NW2 < 2 * P) P /= 2;         // fewer passes than members: nothing to share
+    while (P > 1 && (n - 2) / nsw < 2 * P) P /= 2;         // fewer passes than members: nothing to share
     static Sb16Ctl *s_ctl = nullptr;
     static int cap = 0;
     Sb16Ctl *d_ctl = nullptr;
@@ -1343,23 +1425,29 @@ int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double 
     }
     const int nblk = P > 1 ? ((batch + 7) / 8) * 8 * P : batch;
     const int fab = opts().sb2st_force_abort;
-    const bool rows = opts().sb16_rows != 0;
+    auto launch = [&](long long *dbuf) {
+        if (rows) hipLaunchKernelGGL(band_tail_zero_kernel, dim3(batch), dim3(256), 0, st, n, npad, 2 * hb, d_AB);
+        if (hb == 8)
+            hipLaunchKernelGGL(sbr_rows_kernel<8>, dim3(nblk), dim3(SB16R_THREADS), Rw<8>::LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf,
+                               d_ctl, P, d_status, fab);
+        else if (rows)
+            hipLaunchKernelGGL(sbr_rows_kernel<16>, dim3(nblk), dim3(SB16R_THREADS), Rw<16>::LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf,
+                               d_ctl, P, d_status, fab);
+        else
+            hipLaunchKernelGGL(sb16st_kernel, dim3(nblk), dim3(576), SB16_LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf, d_ctl, P,
+                               d_status, fab);
+    };
     if (opts().sb2st_diag) {                                // cycles per phase of the chasing waves (workgroup 0)
         long long *dbuf = nullptr, h[45];
         BSP_HIP(hipMalloc(reinterpret_cast<void **>(&dbuf), sizeof(h)));
         BSP_HIP(hipMemsetAsync(dbuf, 0, sizeof(h), st));
-        if (rows) {
-            hipLaunchKernelGGL(band_tail_zero_kernel, dim3(batch), dim3(256), 0, st, n, npad, d_AB);
-            hipLaunchKernelGGL(sb16r_kernel, dim3(nblk), dim3(SB16R_THREADS), SB16R_LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf,
-                               d_ctl, P, d_status, fab);
-        }
-        else hipLaunchKernelGGL(sb16st_kernel, dim3(nblk), dim3(576), SB16_LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf, d_ctl, P,
-                                d_status, fab);
+        launch(dbuf);
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) { hipFree(dbuf); BSP_HIP(le); }
         BSP_HIP(hipStreamSynchronize(st));
         BSP_HIP(hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost));
         hipFree(dbuf);
+        fprintf(stderr, "band chase, tiles of %d: %d workgroup(s) per channel, %d per CU\n", hb, P, hb == 8 ? wg8 : 1);
         for (int w = 0; w < 9; ++w) {
             const double steps = h[w * 5 + 4] > 0 ? (double)h[w * 5 + 4] : 1.0;      // workgroup 0 may have left in mode 0: no steps
             fprintf(stderr, "sb16st wave %d: %lld steps; s_memtime ticks per step: chase item %.0f, rest + barrier %.0f (mover wave: columns out %.0f, block in %.0f)\n",
@@ -1369,13 +1457,7 @@ int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double 
         return BSP_OK;
     }
     KScope kt(KS_SB16ST, st);
-    if (rows) {
-        hipLaunchKernelGGL(band_tail_zero_kernel, dim3(batch), dim3(256), 0, st, n, npad, d_AB);
-        hipLaunchKernelGGL(sb16r_kernel, dim3(nblk), dim3(SB16R_THREADS), SB16R_LDS, st, n, npad, batch, d_AB, d_d, d_e,
-                           (long long *)nullptr, d_ctl, P, d_status, fab);
-    }
-    else hipLaunchKernelGGL(sb16st_kernel, dim3(nblk), dim3(576), SB16_LDS, st, n, npad, batch, d_AB, d_d, d_e, (long long *)nullptr,
-                            d_ctl, P, d_status, fab);
+    launch(nullptr);
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }

@@ -680,9 +680,10 @@ def test_variants_at_scale(name, route):
 
 
 def test_band_route_properties():
-    """The band route (csrc/crawford.hip + the band-16 chase) on 12 channels at n = 1024 and on the padded sizes: the same
-    spectra as the dense route to rounding; bit-identical when repeated, for every ring size of the band-16 chase and both
-    fallbacks of its handshake, for the first layout of that chase to rounding; and whatever the batch a channel is solved in."""
+    """The band route (csrc/crawford.hip + the one-column chase on tiles of 8) on 12 channels at n = 1024 and on the padded sizes:
+    the same spectra as the dense route to rounding; bit-identical when repeated, for every ring size of the chase and both
+    fallbacks of its handshake; to rounding with the half-width-15 hand-over and both chases on tiles of 16; and whatever the
+    batch a channel is solved in."""
     prob = capi.Problem(input_from_case("c3_1024_l31"))
     assert prob.route() == 2
     with _Options(route=1):
@@ -704,9 +705,19 @@ def test_band_route_properties():
     with _Options(cw_items4=0):                                # the one-item-per-wave kernel: another summation order
         E, info = prob.solve(0, 12)
     assert np.all(info == 0) and np.max(np.abs(E - E0)) <= 1e-13 * lam
-    with _Options(sb16_rows=0):
-        E, info = prob.solve(0, 12)
-    assert np.max(np.abs(E - E0)) <= 1e-13 * lam
+    # the reduction's result handed over as the block tridiagonal it first was (half-width 15, chase on tiles of 16), with both
+    # layouts of that chase: other roundings of the same matrix
+    with _Options(cw_band8=0):
+        E15, info = prob.solve(0, 12)
+        for kw in [dict(sb2st_ring=4), dict(sb2st_ring=1), dict(sb2st_force_abort=1)]:
+            with _Options(**kw):
+                E, _ = prob.solve(0, 12)
+            assert np.array_equal(E, E15), kw
+        with _Options(sb16_rows=0):
+            E, info2 = prob.solve(0, 12)
+    assert np.all(info == 0) and np.all(info2 == 0)
+    note("band route, half-width 8 vs 15 handed to the chase: normwise %.2e" % (np.max(np.abs(E15 - E0)) / lam))
+    assert np.max(np.abs(E15 - E0)) <= 1e-13 * lam and np.max(np.abs(E - E0)) <= 1e-13 * lam
     E1, _ = prob.solve(0, 1)
     E5, _ = prob.solve(7, 5)
     assert np.array_equal(E1, E0[:1]) and np.array_equal(E5, E0[7:12])

@@ -134,6 +134,20 @@ def test_standard_form(name):
 
 
 # ------------------------------------------------------------------------------------------------
+class _Options:
+    """Flip run-time switches of the library for one test and restore them."""
+    def __init__(self, **kw):
+        self.kw = kw
+    def __enter__(self):
+        self.old = {k: capi.get_option(k) for k in self.kw}
+        for k, v in self.kw.items():
+            capi.set_option(k, v)
+        return self
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            capi.set_option(k, v)
+
+
 def _band_eigs(AB, n, b=64):
     import scipy.linalg as sla
     # AB[j, d] = A(j+d, j): lower band form for scipy (rows = diagonals)
@@ -477,13 +491,20 @@ def test_crawford_band(n, k, nl):
     AB1, _ = capi.stage_crawford(SB, HB[:1])
     assert info == 0
     assert np.array_equal(AB, AB2) and np.array_equal(AB[0], AB1[0])
-    assert np.all(AB[:, :, 16:] == 0.0)
+    assert np.all(AB[:, :, 9:] == 0.0)                           # half-width 8: what the reduction really leaves
+    with _Options(cw_band8=0):                                   # the block tridiagonal as it stands before the last 8 x 8 RQ
+        AB15, info15 = capi.stage_crawford(SB, HB)
+    assert info15 == 0 and np.all(AB15[:, :, 16:] == 0.0) and np.any(AB15[:, :, 9:16] != 0.0)
+    # what the narrow form drops is rounding residue, except in the one block the RQ at the end makes triangular
+    scale = np.max(np.abs(AB15))
+    assert n <= 16 or np.max(np.abs(AB15[:, :n - 16, 9:16])) <= 1e-14 * scale
     for l in range(nl):
         ref = sla.eigh(_dense_upper(HB[l]), _dense_upper(SB), eigvals_only=True)
-        ev = _band_eigs(AB[l], n, 15)
-        err = np.max(np.abs(ev - ref)) / np.max(np.abs(ref))
-        note("crawford n %d k %d l %d: eigenvalues of the band vs scipy eigh(H, S): %.2e of |lambda|_max" % (n, k, l, err))
-        assert err < 2e-14 * np.sqrt(n)                          # both sides carry ~eps cond(S) |lambda|_max
+        for name, A, hw in (("half-width 8", AB, 8), ("half-width 15", AB15, 15)):
+            ev = _band_eigs(A[l], n, hw)
+            err = np.max(np.abs(ev - ref)) / np.max(np.abs(ref))
+            note("crawford n %d k %d l %d, %s: eigenvalues of the band vs scipy eigh(H, S): %.2e of |lambda|_max" % (n, k, l, name, err))
+            assert err < 2e-14 * np.sqrt(n)                      # both sides carry ~eps cond(S) |lambda|_max
 
 
 def test_crawford_not_positive_definite():

@@ -644,3 +644,38 @@ def test_run_token_names_the_launch():
     assert o3.returncode == 0 and o3.stdout.split()[1] != t1, o3.stdout + o3.stderr
     b = __import__("ctypes").create_string_buffer(4)
     assert capi.lib().bspatom_run_token(b, 4) != 0                     # a buffer that cannot hold it is an argument error
+
+
+def test_band_reduction_leaves_half_width_b():
+    """What csrc/crawford.hip's hand-over of a band of half-width 8 rests on, on the dense statement of the blocked reduction
+    (tools/proto_crawford.py::crawford_block): the block tridiagonal result has UPPER TRIANGULAR sub-diagonal blocks E_1 .. E_{N-2}
+    (half-width b) and one full block, E_0 -- also with a ragged last block -- and the eigenvalues are the pencil's."""
+    import scipy.linalg as sla
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import proto_crawford as pc
+    rng = np.random.default_rng(4)
+    for n, b in [(64, 8), (67, 8), (41, 4), (30, 3)]:
+        def band(shift):
+            M = np.zeros((n, n))
+            for d in range(b + 1):
+                v = rng.standard_normal(n - d)
+                i = np.arange(n - d)
+                M[i, i + d] = v
+                M[i + d, i] = v
+            return M + shift * np.eye(n)
+        S, H = band(2.0 * b + 4.0), band(0.0)
+        A = pc.crawford_block(S, H, b)
+        i, j = np.indices(A.shape)
+        scale = np.max(np.abs(A))
+        assert np.max(np.abs(A[np.abs(i - j) > 2 * b - 1])) == 0.0
+        beyond_b = (np.abs(i - j) > b)
+        assert np.max(np.abs(A[beyond_b & (np.minimum(i, j) >= b)])) <= 1e-14 * scale        # E_1 ..: triangular to rounding
+        assert np.max(np.abs(A[beyond_b & (np.minimum(i, j) < b)])) > 1e-3 * scale           # E_0: full
+        # the 8 x 8 RQ at the end: E_0 = R Q^T, D_0 <- Q^T D_0 Q
+        R, Q = sla.rq(A[b:2 * b, :b])
+        T = np.eye(n)
+        T[:b, :b] = Q.T
+        A2 = T.T @ A @ T
+        A2[beyond_b] = 0.0
+        ref = sla.eigh(H, S, eigvals_only=True)
+        assert np.max(np.abs(np.linalg.eigvalsh(A2) - ref)) <= 1e-13 * np.max(np.abs(ref))
