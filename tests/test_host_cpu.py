@@ -570,7 +570,7 @@ def test_two_step_band_reduction_prototype():
 def test_no_scratch_in_the_kernels_of_the_default_route():
     """Round-3 verdict, item 6: the code-object notes of libbspatom.so (llvm-readelf --notes through tools/codeobj_notes.py) -- a
     kernel that the default route of a BASELINE config launches must not use scratch (private_segment_fixed_size = 0).  The band
-    route (configs 1-4: assembly, crawford.hip, the band-16 chase, bisection, the consumed eigenvector, WRITE_WF) has none.  The
+    route (configs 1-4: assembly, crawford.hip, the one-column chase on tiles of 8, bisection, the consumed eigenvector, WRITE_WF) has none.  The
     dense route (config 5, k = 11) still has the listed, capped exceptions; nothing else in the library may spill, and the
     listed ones may not grow."""
     import sys
@@ -588,7 +588,8 @@ def test_no_scratch_in_the_kernels_of_the_default_route():
         "sb2st_kernel_v7<1>": 40,       # the instrumented instance of BSP_SB2ST_DIAG
     }
     band_route = ["point_table_kernel", "band_kernel", "crawford_item_kernel", "crawford_setup_kernel", "crawford_init_kernel",
-                  "crawford_band_kernel", "crawford_flip_kernel", "band_cholesky_kernel", "sb16r_kernel", "band_tail_zero_kernel",
+                  "crawford_band_kernel", "crawford_corner_kernel", "crawford_flip_kernel", "band_cholesky_kernel", "sbr_rows_kernel<8>",
+                  "sbr_rows_kernel<16>", "band_tail_zero_kernel",
                   "bisect3_kernel", "bisect_one3_kernel", "invit_kernel", "wf_kernel"]
     seen = {b: 0 for b in band_route}
     bad = []
