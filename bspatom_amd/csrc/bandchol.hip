@@ -19,11 +19,15 @@ namespace bsp {
 // step: 0.87 us per column, 3.6 ms at n = 4096 -- on the critical path of every solve, of both routes), the pivot goes round by
 // readlane instead of a shuffle through LDS, the wave synchronises with LDS-only waits, and the sum over the previous rows has a
 // fixed trip count with masked addresses (3.8 -> ms at n = 4096: see the loop).
-__global__ __launch_bounds__(64) void band_cholesky_kernel(int n, int k, const double *__restrict__ SB,
-                                                          double *__restrict__ UB,
-                                                          double *__restrict__ rdiag, int *info)
+// Workgroup g factors the band at SB + g * kn (kn = k n) into UB + g * kn, rdiag + g * n, rows 0 .. jstop - 1 only: the band route
+// run from both ends (crawford.hip) wants the leading half of the factor of S and of the index-reversed S, side by side.
+__global__ __launch_bounds__(64) void band_cholesky_kernel(int n, int k, int jstop, const double *__restrict__ SB0,
+                                                          double *__restrict__ UB0,
+                                                          double *__restrict__ rdiag0, int *info)
 {
     constexpr int BMAX = 16, CH = 16, RING = 32;
+    const double *SB = SB0 + (size_t)blockIdx.x * k * n;
+    double *UB = UB0 + (size_t)blockIdx.x * k * n, *rdiag = rdiag0 + (size_t)blockIdx.x * n;
     __shared__ double ring[RING][BMAX + 1];       // ring[p & 31][d] = U(p, p+d) (rows j - b .. j - 1 are live: b <= 16 < 32)
     const int b = k - 1, t = threadIdx.x;
     int bad = 0;
@@ -34,13 +38,13 @@ __global__ __launch_bounds__(64) void band_cholesky_kernel(int n, int k, const d
 #pragma unroll
     for (int c = 0; c < CH; ++c) cur[c] = (row && c < n) ? Sb[c] : 0.0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    for (int j0 = 0; j0 < n; j0 += CH) {
+    for (int j0 = 0; j0 < jstop; j0 += CH) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) { const int j = j0 + CH + c; nxt[c] = (row && j < n) ? Sb[j] : 0.0; }   // in flight during this chunk
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int j = j0 + c;
-            if (j >= n) break;                                           // uniform
+            if (j >= jstop) break;                                       // uniform
             const bool act = row && (j + t < n);
             // S(j, j+t) - sum_{q=1..b} U(j-q, j) U(j-q, j+t): a fixed trip count, addresses by masks (the first version took a
             // run-time modulo per term: ~40 instructions in front of every dependent LDS read, 0.9 us per column); terms beyond
@@ -182,7 +186,16 @@ int launch_band_cholesky(int n, int k, const double *d_SB, double *d_UB, double 
                          hipStream_t st)
 {
     if (k - 1 > 16 || k < 2) return BSP_ERR_ARG;
-    hipLaunchKernelGGL(band_cholesky_kernel, dim3(1), dim3(64), 0, st, n, k, d_SB, d_UB, d_rdiag, d_info);
+    hipLaunchKernelGGL(band_cholesky_kernel, dim3(1), dim3(64), 0, st, n, k, n, d_SB, d_UB, d_rdiag, d_info);
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
+
+// rows 0 .. jstop - 1 of the factors of the two bands at d_SB and d_SB + k n (see the kernel); info is shared: nonzero if either broke down
+int launch_band_cholesky_pair(int n, int k, int jstop, const double *d_SB, double *d_UB, double *d_rdiag, int *d_info, hipStream_t st)
+{
+    if (k - 1 > 16 || k < 2 || jstop < 1 || jstop > n) return BSP_ERR_ARG;
+    hipLaunchKernelGGL(band_cholesky_kernel, dim3(2), dim3(64), 0, st, n, k, jstop, d_SB, d_UB, d_rdiag, d_info);
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }

@@ -67,6 +67,11 @@ struct Options {
     int cw_items4 = 1;           // BSP_CW_ITEMS4: 1 = crawford_item4_kernel (four chase items per wave, an item per DPP row in the RQ loop),
                                  // 0 = crawford_item_kernel (one item per wave; the cross-check)
     int cw_nw = 1;               // BSP_CW_NW: waves per workgroup of crawford_item4_kernel (1 or 4; a wave never talks to another)
+    int cw_split = 0;            // BSP_CW_SPLIT: > 0 = the band reduction runs from both ends of the pencil (n a multiple of 8); the value is the share
+                                 // of the blocks, in percent, of the leading part (at most 50 = half the chase items).  NOT the default: the
+                                 // leading part's fill is chased towards r = 0 and the eigenvalues next to zero pay for it (at 50 %: 21.8 instead
+                                 // of 38.2 ms for the reduction, up to 13 x the error next to zero, 7345 instead of 50 of C4's 524288
+                                 // eigenvalues beyond 1e-10 relative; profiles/r04_experiments.txt, 11).  0 = one process over all blocks
     int cw_band8 = 1;            // BSP_CW_BAND8: 1 = the band reduction hands over the band of half-width 8 it really leaves (one 8 x 8 block
                                  // made triangular at the end) and the chase runs on tiles of 8; 0 = half-width 15, tiles of 16 (as first built)
     int sb8_wgs = 0;             // BSP_SB8_WGS: workgroups of the tiles-of-8 chase per CU the rings are sized for (0 = what fits: 2)
@@ -145,14 +150,16 @@ int launch_dipole_bands(int nfun, int k, int ka, int nkp, const double *d_ptab, 
 // bandchol.hip
 int launch_band_cholesky(int n, int k, const double *d_SB, double *d_UB, double *d_rdiag, int *d_info,
                          hipStream_t st);
+int launch_band_cholesky_pair(int n, int k, int jstop, const double *d_SB, double *d_UB, double *d_rdiag, int *d_info, hipStream_t st);
 // full = 0: C's lower triangle and first block super-diagonal only (all the reduction reads); 1: the whole matrix
 int launch_standard_form(int n, int npad, int k, int nl, const double *d_HB, const double *d_UB,
                          const double *d_rdiag, double *d_Y, double *d_C, hipStream_t st, int full = 0);
 // crawford.hip: band route -- the banded pencil to a banded standard-form matrix (half-width 15) without the dense C_l
 struct CrawfordWork {
-    double *SBf, *UBf, *rdiagf;  // [k][n] overlap in reversed order, its Cholesky factor, [n] reciprocal pivots
-    double *Qel, *LiB;           // [N][256] elimination transforms, [N][64] inverse diagonal blocks of L (N = ceil(n / 8))
-    double *D, *E, *G;           // [nl][N][64] diagonal / sub-diagonal blocks of the working matrix, the fill in flight
+    double *SBf, *UBf, *rdiagf;  // [2][k][n] overlap in reversed order and as it is, their Cholesky factors, [2][n] reciprocal pivots
+    double *Qel, *LiB;           // [2][N][256] elimination transforms, [2][N][64] inverse diagonal blocks of L (N = ceil(n / 8))
+    double *D, *E, *G;           // [nl][2 (N + 2)][64] diagonal / sub-diagonal blocks of the working matrix, the fill in flight (run from
+                                 // both ends: [2 nl][blocks of the longer part + 2][64])
     int *info;                   // device word: order of the minor at which the Cholesky factorisation of the reversed overlap broke down
 };
 bool crawford_supported(int n, int k);

@@ -125,10 +125,16 @@ __device__ __forceinline__ double4_t cw_mfma(double a, double b, double4_t acc)
 
 // Wavefront t: chase items j = jlo .. jlo + nch - 1 (s = t - 2 j, p = j - 2 - s) and, if jel > 0, the elimination of step jel
 // (window (jel - 1, jel)).  grid = (ceil(items / 4), channels), one wave per item.
+// nlh / qstride / nlead: channels blockIdx.y >= nlh take their elimination transforms from Qel + qstride and have nlead blocks (the run
+// from both ends, below: the second half of the batch is the leading part of the pencil, with the factor of S itself)
 template <bool ONEDIV>
-__global__ __launch_bounds__(256) void crawford_item_kernel(int N, int t, int jlo, int nch, int jel,
+__global__ __launch_bounds__(256) void crawford_item_kernel(int N, int t, int jlo, int nch, int jel, int nlh, int qstride, int nlead,
                                                            const double *__restrict__ Qel, double *Dall, double *Eall, double *Gall)
 {
+    if ((int)blockIdx.y >= nlh) {                                          // a leading part of nlead blocks: the items beyond do not exist
+        if (jlo + nch > nlead) nch = nlead > jlo ? nlead - jlo : 0;
+        if (jel >= nlead) jel = 0;
+    }
     const int lane = threadIdx.x & 63;
     const int idx = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15, c8 = c & 7;
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256) void crawford_item_kernel(int N, int t, int jl
         rq_step<1, ONEDIV>(x0, x1, q, g, c);
         rq_step<0, ONEDIV>(x0, x1, q, g, c);
     } else {
-        const double *Qj = Qel + (size_t)j * 256;
+        const double *Qj = Qel + ((int)blockIdx.y >= nlh ? qstride : 0) + (size_t)j * 256;
 #pragma unroll
         for (int r = 0; r < 4; ++r) q[r] = Qj[(4 * r + g) * 16 + c];
         const double *Ej = E + (size_t)(has_x ? j : 0) * CBB;
@@ -317,9 +323,13 @@ __device__ __forceinline__ void rq4_step(double (&x)[16], double (&q)[16], doubl
 }
 
 template <bool ONEDIV, int NW>
-__global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, int t, int jlo, int nch, int jel, int ipw,
-                                                            const double *__restrict__ Qel, double *Dall, double *Eall, double *Gall)
+__global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, int t, int jlo, int nch, int jel, int ipw, int nlh, int qstride,
+                                                            int nlead, const double *__restrict__ Qel, double *Dall, double *Eall, double *Gall)
 {
+    if ((int)blockIdx.y >= nlh) {                                          // a leading part of nlead blocks: the items beyond do not exist
+        if (jlo + nch > nlead) nch = nlead > jlo ? nlead - jlo : 0;
+        if (jel >= nlead) jel = 0;
+    }
     __shared__ __attribute__((aligned(16))) double Qs[NW][4][16 * QLD];  // per wave and item slot: Q, row-major, stride QLD
     __shared__ __attribute__((aligned(16))) double Bc[NW][4][16];        // per wave and item slot: the row that goes round
     const int lane = threadIdx.x & 63;
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
     for (int s = 0; s < 4; ++s) if (kind[s] == 2) se = s;
     const bool has_x = se >= 0 && (jel + 1 <= N - 1);
     if (se >= 0) {
-        const double *Qj = Qel + (size_t)jel * 256;
+        const double *Qj = Qel + ((int)blockIdx.y >= nlh ? qstride : 0) + (size_t)jel * 256;
 #pragma unroll
         for (int r = 0; r < 4; ++r) qe[r] = Qj[(4 * r + g) * 16 + c];
         const double *Ej = E + (size_t)(has_x ? jel : 0) * CBB;
@@ -479,21 +489,27 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
 }
 
 // index-reversed overlap band: SBf[d][i] = S_f(i, i + d) = S(n-1-i-d, n-1-i)
+// ... and, behind it, the band as it is (the pair of factorisations of the run from both ends reads the two side by side)
 __global__ void crawford_flip_kernel(int n, int k, const double *__restrict__ SB, double *__restrict__ SBf)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * k) return;
     const int d = idx / n, i = idx % n;
     SBf[idx] = (i + d < n) ? SB[(size_t)d * n + (n - 1 - i - d)] : 0.0;
+    SBf[(size_t)n * k + idx] = SB[idx];
 }
 
 // Per block j: Li = L_jj^-1, K = Li L_{j,j-1} (L = U^T from the Cholesky factor of the reversed overlap, identity beyond n),
 // LiB[j] = Li (row-major 8 x 8) and Qel[j] = [I -K^T; 0 Li^T] (row-major 16 x 16).  One wave per block.
-__global__ __launch_bounds__(64) void crawford_setup_kernel(int n, int k, const double *__restrict__ UBf, double *__restrict__ LiB,
-                                                           double *__restrict__ Qel)
+// blockIdx.y = which factor (0: of the reversed overlap; 1: of the overlap itself, the run from both ends only), fstride blocks apart in
+// LiB / Qel.
+__global__ __launch_bounds__(64) void crawford_setup_kernel(int n, int k, int fstride, const double *__restrict__ UB0,
+                                                           double *__restrict__ LiB0, double *__restrict__ Qel0)
 {
     __shared__ double Ld[CB][CB + 1], M[CB][CB + 1], Li[CB][CB + 1];
     const int j = blockIdx.x, t = threadIdx.x, r = t >> 3, c = t & 7, b = k - 1;
+    const double *UBf = UB0 + (size_t)blockIdx.y * k * n;
+    double *LiB = LiB0 + (size_t)blockIdx.y * fstride * CBB, *Qel = Qel0 + (size_t)blockIdx.y * fstride * 256;
     const int i = CB * j + r;
     {
         const int ic = CB * j + c, d = r - c;
@@ -535,19 +551,23 @@ __global__ __launch_bounds__(64) void crawford_setup_kernel(int n, int k, const 
 
 // D_p, E_p of the index-reversed H_l (upper band HB[d][i] = H(i, i + d)); block 0 is taken through step 0 of the
 // elimination here: D_0 <- Li_0 D_0 Li_0^T, E_0 <- E_0 Li_0^T.  grid = (N, channels), one wave per block pair.
-__global__ __launch_bounds__(64) void crawford_init_kernel(int n, int k, int N, const double *__restrict__ HBall,
+// Run from both ends (nlh < number of channels in the grid): channel blockIdx.y >= nlh is the LEADING part of the pencil of channel
+// blockIdx.y - nlh in the original order, with Li_0 of the overlap's own factor (LiB + listride); N is the stride of a channel in
+// blocks (the grid has the blocks of a half).
+__global__ __launch_bounds__(64) void crawford_init_kernel(int n, int k, int N, int nlh, int listride, const double *__restrict__ HBall,
                                                           const double *__restrict__ LiB, double *Dall, double *Eall)
 {
     __shared__ double Ds[CB][CB + 1], Es[CB][CB + 1], Ls[CB][CB + 1], Ts[CB][CB + 1];
     const int p = blockIdx.x, t = threadIdx.x, r = t >> 3, c = t & 7, b = k - 1;
-    const double *HB = HBall + (size_t)blockIdx.y * k * n;
-    auto Hf = [&](int i, int i2) -> double {                               // reversed indices
-        const int hi = i > i2 ? i : i2, d = hi - (i > i2 ? i2 : i);
-        return (hi < n && d <= b) ? HB[(size_t)d * n + (n - 1 - hi)] : 0.0;
+    const bool fwd = (int)blockIdx.y >= nlh;
+    const double *HB = HBall + (size_t)(fwd ? blockIdx.y - nlh : blockIdx.y) * k * n;
+    auto Hf = [&](int i, int i2) -> double {                               // reversed indices (original ones for the leading part)
+        const int hi = i > i2 ? i : i2, lo = i > i2 ? i2 : i, d = hi - lo;
+        return (hi < n && d <= b) ? HB[(size_t)d * n + (fwd ? lo : n - 1 - hi)] : 0.0;
     };
     double dv = Hf(CB * p + r, CB * p + c), ev = Hf(CB * (p + 1) + r, CB * p + c);
     if (p == 0) {
-        Ds[r][c] = dv; Es[r][c] = ev; Ls[r][c] = LiB[t];
+        Ds[r][c] = dv; Es[r][c] = ev; Ls[r][c] = LiB[(fwd ? listride : 0) + t];
         __syncthreads();
         double s = 0.0, e2 = 0.0;
 #pragma unroll
@@ -562,6 +582,113 @@ __global__ __launch_bounds__(64) void crawford_init_kernel(int n, int k, int N, 
     const size_t o = ((size_t)blockIdx.y * N + p) * CBB + t;
     Dall[o] = dv;
     Eall[o] = ev;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// THE RUN FROM BOTH ENDS (BSP_CW_SPLIT = share of the leading part in percent; an OPTION, not the default: it is faster -- 21.8
+// instead of 38.2 ms at 128 channels with the cut in the middle -- and it is less accurate next to zero, because the leading part's
+// fill is chased towards r = 0: ORIENTATION above; measured in profiles/r04_experiments.txt, 11).  The fill of elimination step j is
+// chased over j blocks: N^2 / 2 chase items.  Cut the pencil, in the middle say: the trailing part in reversed order (channels
+// 0 .. nl - 1 of the batch, exactly the process above on its first Nh blocks) and the leading part in the original order (channels
+// nl .. 2 nl - 1: the same process with the factor of S itself, Nl = N - Nh <= Nh blocks; the kernels skip the items a shorter part does
+// not have) are two independent pencils -- each chases its fill away from the cut, to its own end of the matrix:
+// 2 (N/2)^2 / 2 = N^2 / 4 items in 3 Nh - 5 launches.  Neither touches the other's blocks: the chase
+// of a part never reaches its last block, and the block that couples the parts is only ever scaled,
+//     C = flip(Li_1) H(cut) Li_0^T   (rows: the leading part's last block, reversed; columns: the trailing part's last block),
+// by the two eliminations next to the cut.  What is left of S is the identity plus the same expression of S's coupling block, Gamma:
+// [I Gamma^T; Gamma I] = [I 0; Gamma C][..]^T with C C^T = I - Gamma Gamma^T, i.e. ONE more elimination step, in the reversed numbering
+// at block Nh with L(Nh, Nh-1) = Gamma, L(Nh, Nh) = C.  Its fill is chased through the trailing part (towards large r: ORIENTATION
+// above): Nh - 1 items, one per launch.  For that sweep the leading part's last block joins the trailing part's arrays as block Nh
+// (a channel has Nh + 2 block slots): D[Nh] = its last diagonal block, flipped, E[Nh] = its last sub-diagonal block, flipped and
+// transposed; crawford_band_kernel reads them back from there.  tools/proto_crawford_split.py states all of it densely.
+//
+// Qel[Nh] of factor 0 = [I -K^T; 0 Li^T] with Li = C^-1, K = Li Gamma.  One wave.
+__global__ __launch_bounds__(64) void crawford_cut_setup_kernel(int n, int k, int N, int Nh, int Nl, const double *__restrict__ SBf,
+                                                               const double *__restrict__ LiB, double *__restrict__ Qel, int *info)
+{
+    __shared__ double A[CB][CB + 1], Lf[CB][CB + 1], T[CB][CB + 1], Gm[CB][CB + 1], Li[CB][CB + 1];
+    const int t = threadIdx.x, r = t >> 3, c = t & 7, b = k - 1;
+    const double *L0 = LiB + (size_t)(Nh - 1) * CBB, *L1 = LiB + (size_t)N * CBB + (size_t)(Nl - 1) * CBB;
+    {
+        const int d = CB + r - c;                                          // S_f(8 Nh + r, 8 (Nh - 1) + c)
+        A[r][c] = (d <= b) ? SBf[(size_t)d * n + CB * (Nh - 1) + c] : 0.0;
+        Lf[r][c] = L1[(CB - 1 - r) * CB + (CB - 1 - c)];
+        Li[r][c] = 0.0;
+    }
+    __syncthreads();
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < CB; ++q) v += Lf[r][q] * A[q][c];
+    T[r][c] = v;
+    __syncthreads();
+    v = 0.0;
+#pragma unroll
+    for (int q = 0; q < CB; ++q) v += T[r][q] * L0[c * CB + q];
+    Gm[r][c] = v;
+    __syncthreads();
+    v = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int q = 0; q < CB; ++q) v -= Gm[r][q] * Gm[c][q];
+    A[r][c] = v;                                                           // I - Gamma Gamma^T
+    __syncthreads();
+    if (t == 0) {                                                          // its Cholesky factor (lower), in place: 8 x 8, one lane
+        for (int j = 0; j < CB; ++j) {
+            double dj = A[j][j];
+            for (int q = 0; q < j; ++q) dj -= A[j][q] * A[j][q];
+            if (!(dj > 0.0)) { if (*info == 0) *info = n; dj = 1.0; }      // S is not positive definite across the cut
+            dj = sqrt(dj);
+            A[j][j] = dj;
+            for (int i = j + 1; i < CB; ++i) {
+                double e = A[i][j];
+                for (int q = 0; q < j; ++q) e -= A[i][q] * A[j][q];
+                A[i][j] = e / dj;
+            }
+        }
+    }
+    __syncthreads();
+    if (t < CB) {                                                          // column t of C^-1 by forward substitution
+        double x[CB];
+#pragma unroll
+        for (int rr = 0; rr < CB; ++rr) {
+            double sacc = (rr == t) ? 1.0 : 0.0;
+#pragma unroll
+            for (int kk = 0; kk < CB; ++kk)
+                if (kk < rr && kk >= t) sacc -= A[rr][kk] * x[kk];
+            x[rr] = (rr >= t) ? sacc / A[rr][rr] : 0.0;
+        }
+#pragma unroll
+        for (int rr = 0; rr < CB; ++rr) Li[rr][t] = x[rr];
+    }
+    __syncthreads();
+    double kv = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < CB; ++kk) kv += Li[r][kk] * Gm[kk][c];           // K[r][c]
+    double *Q = Qel + (size_t)Nh * 256;
+    Q[r * 16 + c] = (r == c) ? 1.0 : 0.0;
+    Q[c * 16 + CB + r] = -kv;
+    Q[(CB + r) * 16 + c] = 0.0;
+    Q[(CB + c) * 16 + CB + r] = Li[r][c];
+}
+
+// Per channel, before the elimination at the cut: the coupling block (E[Nh-1] of the trailing part, scaled from the right by that
+// part's last elimination already) takes the leading part's scaling from the left, and the leading part's last blocks move into
+// slot Nh of the trailing part's arrays.  N = block slots per channel, Nfull = blocks between the two factors in LiB.
+__global__ __launch_bounds__(64) void crawford_cut_prep_kernel(int N, int Nh, int Nl, int nl, int Nfull, const double *__restrict__ LiB,
+                                                              double *Dall, double *Eall)
+{
+    __shared__ double X[CB][CB + 1], Lf[CB][CB + 1];
+    const int t = threadIdx.x, r = t >> 3, c = t & 7;
+    const size_t c0 = (size_t)blockIdx.x * N * CBB, c1 = (size_t)(nl + blockIdx.x) * N * CBB;
+    const double *L1 = LiB + (size_t)Nfull * CBB + (size_t)(Nl - 1) * CBB;
+    X[r][c] = Eall[c0 + (size_t)(Nh - 1) * CBB + t];
+    Lf[r][c] = L1[(CB - 1 - r) * CB + (CB - 1 - c)];
+    __syncthreads();
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < CB; ++q) v += Lf[r][q] * X[q][c];
+    Eall[c0 + (size_t)(Nh - 1) * CBB + t] = v;
+    Dall[c0 + (size_t)Nh * CBB + t] = Dall[c1 + (size_t)(Nl - 1) * CBB + (CB - 1 - r) * CB + (CB - 1 - c)];
+    Eall[c0 + (size_t)Nh * CBB + t] = Eall[c1 + (size_t)(Nl - 2) * CBB + (CB - 1 - c) * CB + (CB - 1 - r)];
 }
 
 // block tridiagonal (reversed order) -> lower band storage of the band-16 chase in the ORIGINAL order:
@@ -634,8 +761,10 @@ __global__ __launch_bounds__(64) void crawford_corner_kernel(int N, double *__re
 
 // hw = half-width handed over: 2 CB - 1 (the block tridiagonal as it stands) or CB (after crawford_corner_kernel; what lies
 // beyond is rounding residue of the RQ factorisations, where LAPACK's own reductions store exact zeros)
-__global__ void crawford_band_kernel(int n, int npad, int N, int hw, const double *__restrict__ Dall, const double *__restrict__ Eall,
-                                     double *__restrict__ ABall)
+// N = block slots per channel; Nh (blocks of the trailing part), Ntot (of the pencil), nl: the run from both ends (Nh = 0: one process
+// over all N blocks)
+__global__ void crawford_band_kernel(int n, int npad, int N, int hw, int Nh, int Ntot, int nl, const double *__restrict__ Dall,
+                                     const double *__restrict__ Eall, double *__restrict__ ABall)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npad * 32) return;
@@ -645,83 +774,122 @@ __global__ void crawford_band_kernel(int n, int npad, int N, int hw, const doubl
     if (j + d < n && d <= hw) {
         const int ihi = n - 1 - j, ilo = ihi - d;                          // reversed indices, ihi >= ilo
         const int P = ihi >> 3, Pc = ilo >> 3;                             // P - Pc = 2 (d >= 9 only): outside the block tridiagonal
-        const double *blk = (P == Pc ? Dall : Eall) + (ch * N + Pc) * CBB;
-        v = (P - Pc <= 1) ? blk[(ihi & 7) * CB + (ilo & 7)] : 0.0;
+        const int rr = ihi & 7, cc = ilo & 7;
+        if (Nh == 0) {
+            const double *blk = (P == Pc ? Dall : Eall) + (ch * N + Pc) * CBB;
+            v = (P - Pc <= 1) ? blk[rr * CB + cc] : 0.0;
+        } else if (P - Pc <= 1) {
+            // run from both ends: blocks 0 .. Nh (diagonal) / 0 .. Nh (sub-diagonal) of the reversed numbering from the trailing part's
+            // arrays, the others from the leading part's (channel nl + ch), flipped: reversed block P is its block Ntot - 1 - P
+            const double *t0 = (P == Pc ? Dall : Eall) + ch * N * CBB, *t1 = (P == Pc ? Dall : Eall) + (nl + ch) * N * CBB;
+            if (Pc <= Nh) v = t0[(size_t)Pc * CBB + rr * CB + cc];
+            else if (P == Pc) v = t1[(size_t)(Ntot - 1 - P) * CBB + (CB - 1 - cc) * CB + (CB - 1 - rr)];   // its lower triangle
+            else v = t1[(size_t)(Ntot - 2 - Pc) * CBB + (CB - 1 - cc) * CB + (CB - 1 - rr)];
+        }
     }
     ABall[ch * ab_stride(npad) + (size_t)j * 128 + d] = v;
 }
 
 }  // namespace
 
+// both forms of the run fit: two bands, two factors, two sets of transforms; 2 (N + 2) block slots per channel (the run from both ends
+// gives each part the slots of the longer one + 2)
 size_t crawford_work_bytes(int n, int k, int nl)
 {
     const size_t N = (n + CB - 1) / CB;
-    return ((size_t)2 * k * n + n + N * 256 + N * CBB + (size_t)3 * nl * N * CBB) * sizeof(double) + 64;
+    return ((size_t)4 * k * n + 2 * n + 2 * N * 256 + 2 * N * CBB + (size_t)3 * nl * 2 * (N + 2) * CBB) * sizeof(double) + 64;
 }
 
 void crawford_carve(void *base, int n, int k, int nl, CrawfordWork *w)
 {
     const size_t N = (n + CB - 1) / CB;
     double *p = static_cast<double *>(base);
-    w->SBf = p; p += (size_t)k * n;
-    w->UBf = p; p += (size_t)k * n;
-    w->rdiagf = p; p += n;
-    w->Qel = p; p += N * 256;
-    w->LiB = p; p += N * CBB;
-    w->D = p; p += (size_t)nl * N * CBB;
-    w->E = p; p += (size_t)nl * N * CBB;
-    w->G = p; p += (size_t)nl * N * CBB;
+    w->SBf = p; p += (size_t)2 * k * n;
+    w->UBf = p; p += (size_t)2 * k * n;
+    w->rdiagf = p; p += 2 * n;
+    w->Qel = p; p += 2 * N * 256;
+    w->LiB = p; p += 2 * N * CBB;
+    w->D = p; p += (size_t)nl * 2 * (N + 2) * CBB;
+    w->E = p; p += (size_t)nl * 2 * (N + 2) * CBB;
+    w->G = p; p += (size_t)nl * 2 * (N + 2) * CBB;
     w->info = reinterpret_cast<int *>(p);
 }
 
 bool crawford_supported(int n, int k) { return k >= 2 && k - 1 <= CB && n >= 2 * CB; }
 
-// d_SB, d_HB: upper bands of S and of nl channels of H; d_AB: the band storage of the band-16 chase (ab_stride per channel).
-// w.info (device) receives the order of the minor of the REVERSED overlap at which its Cholesky factorisation broke down, or 0.
+// w.info (device) receives the order of the minor of the REVERSED overlap at which its Cholesky factorisation broke down, or 0
+// (run from both ends: nonzero if one of the three factorisations broke down -- the caller finds DSYGV's own info with the
+// forward factorisation).
 int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const double *d_HB, const CrawfordWork &w, double *d_AB,
                  hipStream_t st)
 {
     if (!crawford_supported(n, k)) return BSP_ERR_UNSUPPORTED;
     const int N = (n + CB - 1) / CB;
+    // from both ends: both parts whole blocks and long enough to have a chase.  BSP_CW_SPLIT = the share of the blocks, in percent,
+    // that the LEADING part takes (at most half): its fill is chased towards r = 0, which is what costs accuracy (ORIENTATION).
+    int Nl = (opts().cw_split > 0 && n % CB == 0) ? (int)((long)N * (opts().cw_split > 50 ? 50 : opts().cw_split) / 100) : 0;
+    const bool split = Nl >= 3 && N - Nl >= 4;
+    if (!split) Nl = 0;
+    const int Nh = split ? N - Nl : 0;                                     // blocks of the trailing part (the longer one)
+    const int Nproc = split ? Nh : N;                                      // blocks of the longest process
+    const int Ns = split ? Nh + 2 : N;                                     // block slots of a channel of the batch
+    const int ny = split ? 2 * nl : nl;                                    // channels of the batch
+    const int nlead = split ? Nl : 0x7fffffff;
     int rc;
     KScope kt(KS_CRAWFORD, st);
     BSP_HIP(hipMemsetAsync(w.info, 0, sizeof(int), st));
     hipLaunchKernelGGL(crawford_flip_kernel, dim3((n * k + 255) / 256), dim3(256), 0, st, n, k, d_SB, w.SBf);
-    if ((rc = launch_band_cholesky(n, k, w.SBf, w.UBf, w.rdiagf, w.info, st))) return rc;
-    hipLaunchKernelGGL(crawford_setup_kernel, dim3(N), dim3(64), 0, st, n, k, w.UBf, w.LiB, w.Qel);
-    hipLaunchKernelGGL(crawford_init_kernel, dim3(N, nl), dim3(64), 0, st, n, k, N, d_HB, w.LiB, w.D, w.E);
+    if (split) {
+        if ((rc = launch_band_cholesky_pair(n, k, CB * Nh, w.SBf, w.UBf, w.rdiagf, w.info, st))) return rc;
+        hipLaunchKernelGGL(crawford_setup_kernel, dim3(Nh, 2), dim3(64), 0, st, n, k, N, w.UBf, w.LiB, w.Qel);
+        hipLaunchKernelGGL(crawford_cut_setup_kernel, dim3(1), dim3(64), 0, st, n, k, N, Nh, Nl, w.SBf, w.LiB, w.Qel, w.info);
+    } else {
+        if ((rc = launch_band_cholesky(n, k, w.SBf, w.UBf, w.rdiagf, w.info, st))) return rc;
+        hipLaunchKernelGGL(crawford_setup_kernel, dim3(N, 1), dim3(64), 0, st, n, k, N, w.UBf, w.LiB, w.Qel);
+    }
+    hipLaunchKernelGGL(crawford_init_kernel, dim3(Nproc, ny), dim3(64), 0, st, n, k, Ns, nl, N * CBB, d_HB, w.LiB, w.D, w.E);
     BSP_HIP(hipGetLastError());
-    // wavefront t: eliminations 2 j - 1 = t (1 <= j <= N - 1), chase items 2 j + s = t with 0 <= s <= j - 2, j <= N - 1
-    const int tmax = (N >= 3) ? 3 * N - 5 : (N == 2 ? 1 : 0);
-    for (int t = 1; t <= tmax; ++t) {
-        const int jel = ((t & 1) && (t + 1) / 2 <= N - 1) ? (t + 1) / 2 : 0;
-        const int jlo = (t + 2 + 2) / 3;                                  // ceil((t + 2) / 3)
-        const int jhi = (t / 2 < N - 1) ? t / 2 : N - 1;
-        const int nch = (jhi >= jlo && jlo >= 2) ? jhi - jlo + 1 : 0;
+    const int qstride = N * 256;
+    // one wavefront: chase items j = jlo .. jlo + nch - 1 and, if jel > 0, the elimination of step jel, for cy channels
+    auto wavefront = [&](int t, int jlo, int nch, int jel, int cy) {
         const int items = nch + (jel ? 1 : 0);
-        if (items == 0) continue;
         if (opts().cw_items4) {
             const int nw = opts().cw_nw == 4 ? 4 : 1;                      // waves per workgroup (A/B; a wave never talks to another)
-            // items per wave: as few as still fit the chip in one round of resident waves (two per SIMD: 2048)
             // four items per wave at every launch size: fewer (BSP_CW_IPW = 1, 2) on the launches that would still fit the chip
             // was measured and is slower (profiles/r04_experiments.txt, 9) -- a wave's RQ loop costs the same for one item as for four
             const int ipw = (opts().cw_ipw == 1 || opts().cw_ipw == 2) ? opts().cw_ipw : 4;
             const int waves = (items + ipw - 1) / ipw;
-            const dim3 grid((waves + nw - 1) / nw, nl), block(64 * nw);
-            if (opts().cw_onediv) hipLaunchKernelGGL((crawford_item4_kernel<true, 1>), dim3(waves, nl), dim3(64), 0, st, N, t, jlo, nch, jel, ipw, w.Qel, w.D, w.E, w.G);
-            else if (nw == 4) hipLaunchKernelGGL((crawford_item4_kernel<false, 4>), grid, block, 0, st, N, t, jlo, nch, jel, ipw, w.Qel, w.D, w.E, w.G);
-            else hipLaunchKernelGGL((crawford_item4_kernel<false, 1>), grid, block, (size_t)opts().cw_ldspad * 1024, st, N, t, jlo, nch, jel, ipw, w.Qel, w.D, w.E, w.G);
+            const dim3 grid((waves + nw - 1) / nw, cy), block(64 * nw);
+            if (opts().cw_onediv) hipLaunchKernelGGL((crawford_item4_kernel<true, 1>), dim3(waves, cy), dim3(64), 0, st, Ns, t, jlo, nch, jel, ipw, nl, qstride, nlead, w.Qel, w.D, w.E, w.G);
+            else if (nw == 4) hipLaunchKernelGGL((crawford_item4_kernel<false, 4>), grid, block, 0, st, Ns, t, jlo, nch, jel, ipw, nl, qstride, nlead, w.Qel, w.D, w.E, w.G);
+            else hipLaunchKernelGGL((crawford_item4_kernel<false, 1>), grid, block, (size_t)opts().cw_ldspad * 1024, st, Ns, t, jlo, nch, jel, ipw, nl, qstride, nlead, w.Qel, w.D, w.E, w.G);
         } else {
-            const dim3 grid((items + 3) / 4, nl);
-            if (opts().cw_onediv) hipLaunchKernelGGL(crawford_item_kernel<true>, grid, dim3(256), 0, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E, w.G);
-            else hipLaunchKernelGGL(crawford_item_kernel<false>, grid, dim3(256), 0, st, N, t, jlo, nch, jel, w.Qel, w.D, w.E, w.G);
+            const dim3 grid((items + 3) / 4, cy);
+            if (opts().cw_onediv) hipLaunchKernelGGL(crawford_item_kernel<true>, grid, dim3(256), 0, st, Ns, t, jlo, nch, jel, nl, qstride, nlead, w.Qel, w.D, w.E, w.G);
+            else hipLaunchKernelGGL(crawford_item_kernel<false>, grid, dim3(256), 0, st, Ns, t, jlo, nch, jel, nl, qstride, nlead, w.Qel, w.D, w.E, w.G);
         }
+    };
+    // wavefront t: eliminations 2 j - 1 = t (1 <= j <= Nproc - 1), chase items 2 j + s = t with 0 <= s <= j - 2, j <= Nproc - 1
+    const int tmax = (Nproc >= 3) ? 3 * Nproc - 5 : (Nproc == 2 ? 1 : 0);
+    for (int t = 1; t <= tmax; ++t) {
+        const int jel = ((t & 1) && (t + 1) / 2 <= Nproc - 1) ? (t + 1) / 2 : 0;
+        const int jlo = (t + 2 + 2) / 3;                                  // ceil((t + 2) / 3)
+        const int jhi = (t / 2 < Nproc - 1) ? t / 2 : Nproc - 1;
+        const int nch = (jhi >= jlo && jlo >= 2) ? jhi - jlo + 1 : 0;
+        if (nch + (jel ? 1 : 0) == 0) continue;
+        wavefront(t, jlo, nch, jel, ny);
+    }
+    if (split) {
+        // the step at the cut, on the trailing parts (channels 0 .. nl - 1): elimination at block Nh, its fill chased to block 0
+        hipLaunchKernelGGL(crawford_cut_prep_kernel, dim3(nl), dim3(64), 0, st, Ns, Nh, Nl, nl, N, w.LiB, w.D, w.E);
+        wavefront(2 * Nh - 1, 0, 0, Nh, nl);
+        for (int sft = 0; sft <= Nh - 2; ++sft) wavefront(2 * Nh + sft, Nh, 1, 0, nl);
     }
     BSP_HIP(hipGetLastError());
     const bool band8 = opts().cw_band8 != 0;
-    if (band8) hipLaunchKernelGGL(crawford_corner_kernel, dim3(nl), dim3(64), 0, st, N, w.D, w.E);
-    hipLaunchKernelGGL(crawford_band_kernel, dim3((npad * 32 + 255) / 256, nl), dim3(256), 0, st, n, npad, N, band8 ? CB : 2 * CB - 1,
-                       w.D, w.E, d_AB);
+    if (band8) hipLaunchKernelGGL(crawford_corner_kernel, dim3(ny), dim3(64), 0, st, Ns, w.D, w.E);
+    hipLaunchKernelGGL(crawford_band_kernel, dim3((npad * 32 + 255) / 256, nl), dim3(256), 0, st, n, npad, Ns, band8 ? CB : 2 * CB - 1,
+                       Nh, N, nl, w.D, w.E, d_AB);
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }

@@ -705,6 +705,15 @@ def test_band_route_properties():
     with _Options(cw_items4=0):                                # the one-item-per-wave kernel: another summation order
         E, info = prob.solve(0, 12)
     assert np.all(info == 0) and np.max(np.abs(E - E0)) <= 1e-13 * lam
+    # the reduction run from both ends of the pencil (an option: faster, less accurate next to zero -- csrc/crawford.hip): another
+    # sequence of transformations of the same pencil
+    for share in (50, 25):
+        with _Options(cw_split=share):
+            E, info = prob.solve(0, 12)
+            with _Options(cw_items4=0):
+                Eb, _ = prob.solve(0, 12)
+        note("band route, from both ends (leading part %d %%) vs one process: normwise %.2e" % (share, np.max(np.abs(E - E0)) / lam))
+        assert np.all(info == 0) and np.max(np.abs(E - E0)) <= 1e-13 * lam and np.max(np.abs(Eb - E0)) <= 1e-13 * lam
     # the reduction's result handed over as the block tridiagonal it first was (half-width 15, chase on tiles of 16), with both
     # layouts of that chase: other roundings of the same matrix
     with _Options(cw_band8=0):

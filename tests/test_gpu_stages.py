@@ -479,7 +479,7 @@ def _dense_upper(B):
 
 
 @pytest.mark.parametrize("n,k,nl", [(16, 9, 1), (40, 9, 2), (100, 9, 2), (127, 7, 1), (250, 5, 2), (1000, 9, 2), (333, 2, 1),
-                                    (2048, 9, 1)])
+                                    (64, 9, 2), (128, 9, 3), (1024, 6, 2), (2048, 9, 1)])
 def test_crawford_band(n, k, nl):
     """Band route, first stage (csrc/crawford.hip): the banded pencil to a banded standard-form matrix of half-width <= 15.
     Its eigenvalues are the pencil's (scipy's generalized banded solver on the same bands); nothing is stored beyond the
@@ -498,9 +498,15 @@ def test_crawford_band(n, k, nl):
     # what the narrow form drops is rounding residue, except in the one block the RQ at the end makes triangular
     scale = np.max(np.abs(AB15))
     assert n <= 16 or np.max(np.abs(AB15[:, :n - 16, 9:16])) <= 1e-14 * scale
+    halves = []
+    for share in (50, 25, 12):                                   # the run from both ends (BSP_CW_SPLIT; takes effect where 8 | n)
+        with _Options(cw_split=share):
+            ABs, infos = capi.stage_crawford(SB, HB)
+        assert infos == 0 and np.all(ABs[:, :, 9:] == 0.0)
+        halves.append(("leading part %d %%" % share, ABs, 8))
     for l in range(nl):
         ref = sla.eigh(_dense_upper(HB[l]), _dense_upper(SB), eigvals_only=True)
-        for name, A, hw in (("half-width 8", AB, 8), ("half-width 15", AB15, 15)):
+        for name, A, hw in [("half-width 8", AB, 8), ("half-width 15", AB15, 15)] + halves:
             ev = _band_eigs(A[l], n, hw)
             err = np.max(np.abs(ev - ref)) / np.max(np.abs(ref))
             note("crawford n %d k %d l %d, %s: eigenvalues of the band vs scipy eigh(H, S): %.2e of |lambda|_max" % (n, k, l, name, err))

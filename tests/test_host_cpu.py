@@ -680,3 +680,34 @@ def test_band_reduction_leaves_half_width_b():
         A2[beyond_b] = 0.0
         ref = sla.eigh(H, S, eigvals_only=True)
         assert np.max(np.abs(np.linalg.eigvalsh(A2) - ref)) <= 1e-13 * np.max(np.abs(ref))
+
+
+def test_band_reduction_from_both_ends():
+    """The dense statement of csrc/crawford.hip's run from both ends (tools/proto_crawford_split.py::crawford_split; its own
+    assertions check that what is left of S after the two independent parts is the identity plus ONE block next to the cut): half
+    the chase items of the one-sided process, the pencil's eigenvalues, half-width b away from the two end blocks."""
+    import scipy.linalg as sla
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import proto_crawford_split as ps
+    rng = np.random.default_rng(9)
+    for n, b in [(64, 8), (96, 8), (48, 4)]:
+        def band(shift):
+            M = np.zeros((n, n))
+            for d in range(b + 1):
+                v = rng.standard_normal(n - d)
+                i = np.arange(n - d)
+                M[i, i + d] = v
+                M[i + d, i] = v
+            return M + shift * np.eye(n)
+        S, H = band(2.0 * b + 4.0), band(0.0)
+        cnt = [0]
+        A = ps.crawford_split(S, H, b, n // 2, cnt)
+        N = n // b
+        assert cnt[0] == 2 * ((N // 2 - 1) * (N // 2 - 2) // 2) + (N // 2 - 1) and cnt[0] < 0.62 * ((N - 1) * (N - 2) // 2)
+        i, j = np.indices(A.shape)
+        scale = np.max(np.abs(A))
+        assert np.max(np.abs(A[np.abs(i - j) > 2 * b - 1])) == 0.0
+        inner = (np.abs(i - j) > b) & (np.minimum(i, j) >= b) & (np.maximum(i, j) < n - b)
+        assert np.max(np.abs(A[inner])) <= 1e-14 * scale
+        ref = sla.eigh(H, S, eigvals_only=True)
+        assert np.max(np.abs(np.linalg.eigvalsh((A + A.T) / 2) - ref)) <= 1e-13 * np.max(np.abs(ref))

@@ -3,7 +3,7 @@ set -o pipefail
 O=gpurun_out/r4l; mkdir -p $O; rm -f $O/times.txt $O/err.txt
 timeout -k 10 600 python -m pytest tests/test_gpu_stages.py tests/test_gpu_solve.py -x -q -k "crawford or band_route" > $O/pytest.log 2>&1 || { tail -40 $O/pytest.log | cut -c1-300; exit 1; }
 tail -1 $O/pytest.log
-for ch in 128 64 32 16; do for v in "cw_band8=0" "cw_band8=1" "cw_band8=1 sb8_wgs=1"; do
+for ch in 128 64 32 16; do for v in "cw_split=0" "cw_split=1"; do
   timeout -k 10 200 python tools/stage_times.py --channels $ch --reps 5 $v >> $O/times.txt 2>> $O/err.txt || { tail -5 $O/err.txt; exit 1; }
 done; done
 cat $O/times.txt
