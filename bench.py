@@ -4,8 +4,8 @@
 One "step" = one pass of the hot path over one batch of l-channels per GPU, inputs resident in HBM:
   assembly of S and H(l) bands -> reduction to a band matrix -> tridiagonal -> bisection (all nfun eigenvalues of every
   channel) + the (l_ini, n0_ini) eigenvector and its WRITE_WF table on the rank that owns l_ini + the RCCL all-gather of the
-  spectra.  The library's default route for k <= 9 is the BAND route (csrc/crawford.hip: the pencil stays banded, band-16
-  chase); the DENSE route (banded Cholesky -> standard form -> sy2sb -> two-step bulge chasing: north_star's letter) is measured
+  spectra.  The library's default route for k <= 9 is the BAND route (csrc/crawford.hip: the pencil stays banded at half-width 8,
+  one-column chase on tiles of 8); the DENSE route (banded Cholesky -> standard form -> sy2sb -> two-step bulge chasing: north_star's letter) is measured
   in the same run as `dense_two_stage` (a few extra untimed-for-`value` steps) and is what `--route 1` makes `value`.
 Workload (BASELINE configs[3], "Hydrogen l=0..127, N_bsp=4096"): KIND_GRID=0 ra=0 rb=800 k=9
 nfun=4096 Zatom=1.  The l-loop being sharded is reference matrices.f90:242-248.
@@ -364,15 +364,15 @@ def flop_dense(n, k):
 
 
 def flop_band(n):
-    """Algorithmic flop per l-channel of the band route (csrc/crawford.hip + band-16 chase + bisection), stated in DESIGN.md 4.5:
+    """Algorithmic flop per l-channel of the band route (csrc/crawford.hip + one-column chase + bisection), stated in DESIGN.md 4.5:
     chase items (N-1)(N-2)/2 with N = ceil(n/8), each the RQ of an 8 x 16 block (2*16*64 - 2/3*512), its 16 x 16 factor formed
     (8 reflectors x 4*256), the congruence Q^T (W Q) (2 products of 2*16^3) and Q^T [E; 0] (2*16*8*8); N - 1 eliminations (the two
-    products and the two small ones); band 16 -> 1: 6 n^2 16; bisection: 54 Sturm counts of n rows for n eigenvalues, 3 fp64
-    operations per row."""
+    products and the two small ones); band of half-width 8 -> tridiagonal: 6 n^2 8; bisection: 54 Sturm counts of n rows for n
+    eigenvalues, 3 fp64 operations per row."""
     N = (n + 7) // 8
     item = (2 * 16 * 64 - 2.0 / 3.0 * 512) + 8 * 4 * 256 + 2 * 2 * 16 ** 3 + 2 * 16 * 8 * 8
     elim = 2 * 2 * 16 ** 3 + 2 * 2 * 16 * 8 * 8
-    return {"band_reduction": (N - 1) * (N - 2) / 2.0 * item + (N - 1) * elim, "band16_chase": 6.0 * n * n * 16,
+    return {"band_reduction": (N - 1) * (N - 2) / 2.0 * item + (N - 1) * elim, "band_chase": 6.0 * n * n * 8,
             "bisect": 54.0 * 3.0 * n * n}
 
 
@@ -403,7 +403,7 @@ def dense_kernel_entries(ktimes, npad, nl, pmc_bytes, pmc_file, pmc_stale, mfma,
     other = {"panel_qr": dict(zip(("kernel_ms_per_step", "launches_per_step"), kt("panel_qr"))),
              "sy2sb_chain_small_products": dict(zip(("kernel_ms_per_step", "launches_per_step"), kt("sy2sb chain"))),
              "sb2sb_mfma_kernel": dict(zip(("kernel_ms_per_step", "launches_per_step"), kt("sb2sb_mfma"))),
-             "sb16r_kernel": dict(zip(("kernel_ms_per_step", "launches_per_step"), kt("sb16"))),
+             "sbr_rows_kernel<16>": dict(zip(("kernel_ms_per_step", "launches_per_step"), kt("sbr_rows"))),
              "bisect3_kernel": dict(zip(("kernel_ms_per_step", "launches_per_step"), kt("bisect3"))),
              "cholesky_std_form": dict(zip(("kernel_ms_per_step", "launches_per_step"), kt("std_form")))}
     return kern, other
@@ -508,7 +508,7 @@ def report(args, world, n, npad, main, ktimes, kstage, route):
                    "no committed counter profile of this route and workload"
     if route == 2:
         # ---- band route: three kernels of comparable weight.  The reduction and the bisection compute on the fp64 vector / matrix
-        # datapath (one peak on gfx950: 78.6 TFLOP/s), the band-16 chase streams the band through LDS windows (HBM model).
+        # datapath (one peak on gfx950: 78.6 TFLOP/s), the one-column chase streams the band through LDS windows (HBM model).
         fb = flop_band(n)
         N = (n + 7) // 8
         kern = []
@@ -516,7 +516,7 @@ def report(args, world, n, npad, main, ktimes, kstage, route):
         if calls:
             ach = fb["band_reduction"] * nl / (ms_sum * 1e-3) / 1e12
             items = (N - 1) * (N - 2) // 2
-            kern.append({"kernel": "crawford_item4_kernel (+ its set-up kernels; crawford_item_kernel with BSP_CW_ITEMS4=0; csrc/crawford.hip)", "what": "banded pencil -> band 15: "
+            kern.append({"kernel": "crawford_item4_kernel (+ its set-up kernels; crawford_item_kernel with BSP_CW_ITEMS4=0; csrc/crawford.hip)", "what": "banded pencil -> band of half-width 8: "
                          "%d chase items of 8 x 8 blocks per channel in %d wavefront launches" % (items, 3 * N - 5), "bound": "mfma",
                          "launches_per_step": 3 * N - 5 + 5, "kernel_ms_per_step": ms_sum, "avg_launch_ms": ms_sum / (3 * N),
                          "launch_ms_source": "HIP events around the whole stage, one extra untimed step of this run (bspatom_kernel_times)",
@@ -528,14 +528,17 @@ def report(args, world, n, npad, main, ktimes, kstage, route):
                          "limited_by": "issue and latency at two waves per SIMD (250 registers): ~640 instructions per item, the serial sqrt / "
                                        "division chain of eight reflectors, 12 fp64 MFMAs (on gfx950 an fp64 MFMA costs what its 1024 "
                                        "multiply-adds cost on the vector pipe); wavefront launches quantise the occupancy"})
-        ms_sum, calls = kt("sb16")
-        b2 = sum(2 * 32 * 8 * (n - s0_) for s0_ in range(0, n - 2, 8)) * nl
+        ms_sum, calls = kt("sbr_rows")
+        # tiles of 8: a pass of 16 sweeps streams the remaining band (window columns of 16 rows) in and out once
+        b2 = sum(2 * 16 * 8 * (n - s0_) for s0_ in range(0, n - 2, 16)) * nl
         if calls:
-            kern.append({"kernel": next(k for k in ktimes if "sb16" in k), "bound": "hbm", "launches_per_step": calls, "avg_launch_ms": ms_sum / calls,
+            kern.append({"kernel": next(k for k in ktimes if "sbr_rows" in k), "what": "band of half-width 8 -> tridiagonal, tiles of 8 "
+                         "(sbr_rows_kernel<8>)", "bound": "hbm", "launches_per_step": calls, "avg_launch_ms": ms_sum / calls,
                          "kernel_ms_per_step": ms_sum, "launch_ms_source": src_live, "bytes_model_per_step": b2,
                          "achieved": b2 / (ms_sum * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b2 / (ms_sum * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": pmc_bytes("sb16"), "traffic_source": pmc_file, "traffic_stale": pmc_stale,
-                         "limited_by": "serial chase, one item per sweep and step: the LDS pipe and the latency of an item's dependent chains"})
+                         "traffic": pmc_bytes("sbr_rows"), "traffic_source": pmc_file, "traffic_stale": pmc_stale,
+                         "limited_by": "serial chase, one item per sweep and step: the LDS pipe (~176 LDS instructions per step of a workgroup, two workgroups per CU) "
+                                       "and the latency of an item's dependent chains"})
         ms_sum, calls = kt("bisect3")
         if calls:
             ach = fb["bisect"] * nl / (ms_sum * 1e-3) / 1e12
@@ -547,10 +550,10 @@ def report(args, world, n, npad, main, ktimes, kstage, route):
         ach = F * main["value"] / 1e12
         ceiling = FP64_PEAK_TFLOPS * 1e12 * world / flop_dense(n, args.k)
         roof = {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS * world, "unit": "TFLOP/s", "frac": ach / (FP64_PEAK_TFLOPS * world),
-                "scope": "whole path, BAND route: F_band(n) = %.3g flop per l-channel (band reduction %.3g + band-16 chase %.3g + bisection %.3g; "
+                "scope": "whole path, BAND route: F_band(n) = %.3g flop per l-channel (band reduction %.3g + one-column chase %.3g + bisection %.3g; "
                          "bench.py::flop_band, DESIGN.md 4.5) x eigensolves/s, against the fp64 vector = matrix peak of %d GPU(s).  The route "
                          "does 1/%.0f of the dense algorithm's arithmetic (SURVEY 8d: F(n) = %.3g): see `dense_algorithm_ceiling`"
-                         % (F, fb["band_reduction"], fb["band16_chase"], fb["bisect"], world, flop_dense(n, args.k) / F, flop_dense(n, args.k)),
+                         % (F, fb["band_reduction"], fb["band_chase"], fb["bisect"], world, flop_dense(n, args.k) / F, flop_dense(n, args.k)),
                 "dense_algorithm_ceiling": {"eigensolves_per_s_at_100_percent_of_fp64_peak": ceiling,
                                             "value_over_ceiling": main["value"] / ceiling,
                                             "note": "F(n) = 4/3 n^3 + 4 n^2 k per channel: no implementation of the dense two-stage route can "

@@ -112,7 +112,7 @@ hipEvent_t kevent()
 }
 const char *const KSLOT_NAMES[KS_COUNT] = {"gemm2_kernel<128,128,MODE 1> (rank-128 update, syr2k)", "gemm2_kernel<64,128,MODE 2> (symm Y = A22 W)",
                                           "panel_qr2_kernel / panel_qr_kernel", "sy2sb chain: G, K (split-K gemm_kernel + splitk_reduce), form_T, tsmm64 (W, Z)",
-                                          "sb2sb_mfma_kernel (band 64 -> 16)", "sb16r_kernel / sb16st_kernel (band 16 -> 1)", "bisect3_kernel",
+                                          "sb2sb_mfma_kernel (band 64 -> 16)", "sbr_rows_kernel<8> / <16> / sb16st_kernel (one-column chase to tridiagonal)", "bisect3_kernel",
                                           "band_cholesky_kernel + std_form_kernel",
                                           "crawford_item_kernel and its set-up kernels (band route: pencil -> band 15)"};
 }  // namespace
