@@ -355,7 +355,7 @@ def run(args):
 
 
 STAGES_DENSE = ["assemble", "chol_std", "sy2sb", "sb2st", "bisect"]
-STAGES_BAND = ["assemble", "(unused)", "band_reduction", "band16_chase", "bisect"]
+STAGES_BAND = ["assemble", "(unused)", "band_reduction", "band_chase", "bisect"]
 
 
 def flop_dense(n, k):
