@@ -8,8 +8,9 @@
 //   Step j ("elimination"): A <- R_j^-1 A R_j^-T touches block row / column j only and leaves ONE 8 x 8 block of fill, at
 //   (j, j-2).  It is chased off the top: item (j, s), p = j - 2 - s, takes the RQ factorisation [A(p+2,p), A(p+2,p+1)] = [0 R] Q^T
 //   and applies Q to block columns and rows (p, p+1), which moves the fill to (p+1, p-1).  Q mixes blocks below j only and
-//   therefore commutes with every later R_k.  The result is block tridiagonal with full 8 x 8 blocks: half-width 15, the input
-//   of the band-16 chase (sbr2.hip); 6 n^2 b flop instead of 4/3 n^3.
+//   therefore commutes with every later R_k.  The result is block tridiagonal -- and, the sub-diagonal blocks being upper triangular
+//   at the end of every sweep (crawford_corner_kernel below), of half-width 8: the input of the one-column chase on tiles of 8
+//   (sbr2.hip::sbr_rows_kernel<8>); 6 n^2 b flop instead of 4/3 n^3.
 //
 // Both kinds of work are ONE shape: a 16 x 16 matrix Q applied as a congruence to the window W = [D_p E_p^T; E_p D_{p+1}] and
 // from the left to the block in front of it, [E_{p-1}; 0] -> [E_{p-1}'; fill].  For a chase item Q is orthogonal (eight

@@ -11,12 +11,13 @@
 //          less often.  Items (sweep s, step k) with k + 3 s = t are independent (their tile sets are disjoint,
 //          tools/proto_sbr.py checks it), so ONE LAUNCH PER WAVEFRONT t orders everything: no flags, no spinning,
 //          bit-identical results by construction.
-//   step 2 (sb16r_kernel; sb16st_kernel = the first layout, kept as its cross-check, BSP_SB16_ROWS=0): one-column chase of the
-//          band of half-width 16.  A workgroup runs 8 consecutive sweeps, three items apart, on a sliding window of the band
+//   step 2 (sbr_rows_kernel<16> -- "sb16r_kernel" in round 3's notes; sb16st_kernel = the first layout, kept as its cross-check,
+//          BSP_SB16_ROWS=0): one-column chase of the band of half-width 16.  Round 4: the same kernel with tiles of 8,
+//          sbr_rows_kernel<8>, is the band route's chase (the band crawford.hip leaves has half-width 8).  A workgroup runs 8 consecutive sweeps, three items apart, on a sliding window of the band
 //          held in LDS (512 columns x 32 rows: the band and what the sweeps leave of their bulges, which stays in the matrix
 //          between passes) + one wave that only moves data; HBM sees each pass of 8 sweeps once.  P = 1 .. 8 workgroups share
 //          the passes of a channel (Sb16Ctl).  sb16st_kernel: one wave per sweep, a 16 x 16 tile spread over the wave;
-//          sb16r_kernel: a chase item per row of 16 lanes, four sweeps per wave, three waves (roles) per four sweeps.
+//          sbr_rows_kernel<B>: a chase item per 16 (8) lanes, four (eight) sweeps per wave, three waves (roles) per group of sweeps.
 // Index conventions, the lag of 3 and the working band (<= 127 / <= 31 sub-diagonals) are those of tools/proto_sbr.py.
 // Band storage as everywhere: AB[d + 128 j] = A(j + d, j) (sy2sb.hip::extract_band_kernel).
 #include "common.h"

@@ -130,7 +130,7 @@ int bspatom_last_timing(const bspatom_problem *p, double ms[6]);
  * of the kernels below is bracketed by two HIP events on its own stream; this call waits for the device, sums the elapsed
  * times and launch counts per slot since the previous call into ms[] / launches[] (cap >= the slot count, which it returns)
  * and forgets them.  Slots: 0 rank-128 update (syr2k), 1 symm, 2 panel QR, 3 the small products of the panel chain,
- * 4 sb2sb_mfma_kernel, 5 sb16r_kernel (sb16st_kernel with BSP_SB16_ROWS=0), 6 batched bisection, 7 Cholesky + standard form,
+ * 4 sb2sb_mfma_kernel, 5 sbr_rows_kernel<8> / <16> (sb16st_kernel with BSP_SB16_ROWS=0), 6 batched bisection, 7 Cholesky + standard form,
  * 8 the band route's reduction (crawford.hip); bspatom_kernel_slot_name(i)
  * names them.  Launches on different streams overlap: the sums are sums of launch durations, not wall time. */
 int bspatom_kernel_times(double *ms, int32_t *launches, int cap);
