@@ -31,6 +31,7 @@
 // next to zero lose a factor of 50 at l = 14 (0.015 against 0.0003 eps lambda_max, measured against 113-bit truth by the
 // prototype).  The band handed to the tridiagonalisation is stored in the original order again.
 #include "common.h"
+#include <cstdio>
 
 namespace bsp {
 namespace {
@@ -325,8 +326,13 @@ __device__ __forceinline__ void rq4_step(double (&x)[16], double (&q)[16], doubl
 
 template <bool ONEDIV, int NW>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, int t, int jlo, int nch, int jel, int ipw, int nlh, int qstride,
-                                                            int nlead, const double *__restrict__ Qel, double *Dall, double *Eall, double *Gall)
+                                                            int nlead, const double *__restrict__ Qel, double *Dall, double *Eall, double *Gall,
+                                                            unsigned long long *diag)
 {
+    // BSP_CW_DIAG: s_memtime stamps of a wave's phases, summed over the waves of every launch (diag[0..6] ticks, diag[7] waves)
+    unsigned long long ts0 = 0, tsa = 0, tsb = 0, tsc = 0, tsd = 0, tse = 0;
+    if (diag && (((blockIdx.x & 7) | (blockIdx.y & 7)) != 0)) diag = nullptr;   // one wave in 64 reports (the sums are atomics)
+    if (diag) ts0 = __builtin_amdgcn_s_memtime();
     if ((int)blockIdx.y >= nlh) {                                          // a leading part of nlead blocks: the items beyond do not exist
         if (jlo + nch > nlead) nch = nlead > jlo ? nlead - jlo : 0;
         if (jel >= nlead) jel = 0;
@@ -362,6 +368,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
 #pragma unroll
         for (int c = 0; c < 16; ++c) q[c] = (c == r) ? 1.0 : 0.0;
         double *bc = &Bc[wave][it][0];
+        if (diag) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tsa = __builtin_amdgcn_s_memtime(); }   // X has arrived
         rq4_step<7, ONEDIV>(x, q, bc, r);
         rq4_step<6, ONEDIV>(x, q, bc, r);
         rq4_step<5, ONEDIV>(x, q, bc, r);
@@ -370,6 +377,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
         rq4_step<2, ONEDIV>(x, q, bc, r);
         rq4_step<1, ONEDIV>(x, q, bc, r);
         rq4_step<0, ONEDIV>(x, q, bc, r);
+        if (diag) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tsb = __builtin_amdgcn_s_memtime(); }   // the eight reflectors
         if (live) {                                                      // E_{p+1} <- R
             double *ep = E + (size_t)(p + 1) * CBB + r * CB;
 #pragma unroll
@@ -383,6 +391,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
     // Everything phase B computes from the kernel's arguments (item numbers, block addresses of four items) would otherwise be
     // hoisted in front of phase A and sit in registers across it (96 dwords spilled at three waves per SIMD): the two values it
     // all derives from are redefined here, as far as the compiler can tell.
+    if (diag) tsc = __builtin_amdgcn_s_memtime();                        // R and Q stored
     int idx0b = idx0;
     size_t chnb = chn;
     asm volatile("" : "+s"(idx0b), "+s"(chnb));
@@ -435,6 +444,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
             xt[r] = (has_x && left) ? v : 0.0;
         }
     }
+    if (diag) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tsd = __builtin_amdgcn_s_memtime(); }   // phase B's operands have arrived
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         if (kind[s] == 0) break;
@@ -485,6 +495,22 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
 #pragma unroll
                 for (int r = 0; r < 2; ++r) Ej[c8 * CB + 4 * r + g] = T[r + 2];
             }
+        }
+    }
+    if (diag) {
+        tse = __builtin_amdgcn_s_memtime();                              // the congruences issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tsf = __builtin_amdgcn_s_memtime();    // the stores have left
+        if (lane == 0) {
+            const bool a = tsa != 0;
+            atomicAdd(diag + 0, a ? tsa - ts0 : 0ull);
+            atomicAdd(diag + 1, a ? tsb - tsa : 0ull);
+            atomicAdd(diag + 2, a ? tsc - tsb : tsc - ts0);
+            atomicAdd(diag + 3, tsd - tsc);
+            atomicAdd(diag + 4, tse - tsd);
+            atomicAdd(diag + 5, tsf - tse);
+            atomicAdd(diag + 6, tsf - ts0);
+            atomicAdd(diag + 7, 1ull);
         }
     }
 }
@@ -852,6 +878,11 @@ int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const doubl
     BSP_HIP(hipGetLastError());
     const int qstride = N * 256;
     // one wavefront: chase items j = jlo .. jlo + nch - 1 and, if jel > 0, the elimination of step jel, for cy channels
+    unsigned long long *dg = nullptr;
+    if (opts().cw_diag && opts().cw_items4) {
+        BSP_HIP(hipMalloc(reinterpret_cast<void **>(&dg), 8 * sizeof(unsigned long long)));
+        BSP_HIP(hipMemsetAsync(dg, 0, 8 * sizeof(unsigned long long), st));
+    }
     auto wavefront = [&](int t, int jlo, int nch, int jel, int cy) {
         const int items = nch + (jel ? 1 : 0);
         if (opts().cw_items4) {
@@ -861,9 +892,9 @@ int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const doubl
             const int ipw = (opts().cw_ipw == 1 || opts().cw_ipw == 2) ? opts().cw_ipw : 4;
             const int waves = (items + ipw - 1) / ipw;
             const dim3 grid((waves + nw - 1) / nw, cy), block(64 * nw);
-            if (opts().cw_onediv) hipLaunchKernelGGL((crawford_item4_kernel<true, 1>), dim3(waves, cy), dim3(64), 0, st, Ns, t, jlo, nch, jel, ipw, nl, qstride, nlead, w.Qel, w.D, w.E, w.G);
-            else if (nw == 4) hipLaunchKernelGGL((crawford_item4_kernel<false, 4>), grid, block, 0, st, Ns, t, jlo, nch, jel, ipw, nl, qstride, nlead, w.Qel, w.D, w.E, w.G);
-            else hipLaunchKernelGGL((crawford_item4_kernel<false, 1>), grid, block, (size_t)opts().cw_ldspad * 1024, st, Ns, t, jlo, nch, jel, ipw, nl, qstride, nlead, w.Qel, w.D, w.E, w.G);
+            if (opts().cw_onediv) hipLaunchKernelGGL((crawford_item4_kernel<true, 1>), dim3(waves, cy), dim3(64), 0, st, Ns, t, jlo, nch, jel, ipw, nl, qstride, nlead, w.Qel, w.D, w.E, w.G, dg);
+            else if (nw == 4) hipLaunchKernelGGL((crawford_item4_kernel<false, 4>), grid, block, 0, st, Ns, t, jlo, nch, jel, ipw, nl, qstride, nlead, w.Qel, w.D, w.E, w.G, dg);
+            else hipLaunchKernelGGL((crawford_item4_kernel<false, 1>), grid, block, (size_t)opts().cw_ldspad * 1024, st, Ns, t, jlo, nch, jel, ipw, nl, qstride, nlead, w.Qel, w.D, w.E, w.G, dg);
         } else {
             const dim3 grid((items + 3) / 4, cy);
             if (opts().cw_onediv) hipLaunchKernelGGL(crawford_item_kernel<true>, grid, dim3(256), 0, st, Ns, t, jlo, nch, jel, nl, qstride, nlead, w.Qel, w.D, w.E, w.G);
@@ -887,6 +918,16 @@ int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const doubl
         for (int sft = 0; sft <= Nh - 2; ++sft) wavefront(2 * Nh + sft, Nh, 1, 0, nl);
     }
     BSP_HIP(hipGetLastError());
+    if (dg) {
+        unsigned long long h[8];
+        BSP_HIP(hipStreamSynchronize(st));
+        BSP_HIP(hipMemcpy(h, dg, sizeof(h), hipMemcpyDeviceToHost));
+        hipFree(dg);
+        const double wv = h[7] ? (double)h[7] : 1.0;
+        fprintf(stderr, "crawford_item4_kernel, %llu waves, s_memtime ticks per wave: X arrives %.0f | eight reflectors %.0f | R, Q stored %.0f | "
+                        "phase B operands arrive %.0f | congruences issued %.0f | stores leave %.0f | wave %.0f\n", h[7], h[0] / wv, h[1] / wv,
+                h[2] / wv, h[3] / wv, h[4] / wv, h[5] / wv, h[6] / wv);
+    }
     const bool band8 = opts().cw_band8 != 0;
     if (band8) hipLaunchKernelGGL(crawford_corner_kernel, dim3(ny), dim3(64), 0, st, Ns, w.D, w.E);
     hipLaunchKernelGGL(crawford_band_kernel, dim3((npad * 32 + 255) / 256, nl), dim3(256), 0, st, n, npad, Ns, band8 ? CB : 2 * CB - 1,
