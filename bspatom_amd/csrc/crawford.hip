@@ -291,8 +291,12 @@ __device__ __forceinline__ void rq4_step(double (&x)[16], double (&q)[16], doubl
     const double nrm = sqrt(ok ? a2s : 1.0);
     const double bt = (alpha >= 0.0) ? -nrm : nrm;
     const double amb = alpha - bt;
-    const double sc = ONEDIV ? 1.0 : (ok ? 1.0 / amb : 0.0);
-    const double t = ok ? (ONEDIV ? -1.0 / (bt * amb) : (bt - alpha) / bt) : 0.0;
+    // the two divisions on operands that are safe either way and the results masked by a multiplication (x * 1.0 and x * 0.0 are
+    // exact): written as selects of the quotients, the compiler puts each division under a branch of its own and the two
+    // dependent sequences of eleven instructions run one after the other instead of side by side
+    const double okf = ok ? 1.0 : 0.0, ambs = ok ? amb : 1.0, bts = ok ? bt : 1.0;
+    const double sc = ONEDIV ? 1.0 : (1.0 / ambs) * okf;
+    const double t = (ONEDIV ? -1.0 / (bts * ambs) : (bts - alpha) / bts) * okf;
     const double beta = ok ? bt : alpha;
     if (!ONEDIV) {
 #pragma unroll
