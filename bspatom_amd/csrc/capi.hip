@@ -74,7 +74,7 @@ const OptName OPT_TABLE[] = {
     {"sy2sb_segs", "BSP_SY2SB_SEGS", &Options::sy2sb_segs}, {"panel_qr", "BSP_PANEL_QR", &Options::panel_qr},
     {"gemm_diag", "BSP_GEMM_DIAG", &Options::gemm_diag}, {"bisect", "BSP_BISECT", &Options::bisect},
     {"bisect_ept", "BSP_BISECT_EPT", &Options::bisect_ept},
-    {"bisect_tail", "BSP_BISECT_TAIL", &Options::bisect_tail}, {"no_eigvec_prefetch", "BSP_NO_EIGVEC_PREFETCH", &Options::no_eigvec_prefetch},
+    {"bisect_tail", "BSP_BISECT_TAIL", &Options::bisect_tail}, {"bisect_secant", "BSP_BISECT_SECANT", &Options::bisect_secant}, {"no_eigvec_prefetch", "BSP_NO_EIGVEC_PREFETCH", &Options::no_eigvec_prefetch},
     {"poison_c", "BSP_POISON_C", &Options::poison_c}, {"sb2sb_mfma", "BSP_SB2SB_MFMA", &Options::sb2sb_mfma},
     {"ktime", "BSP_KTIME", &Options::ktime}, {"tsqr_regcap", "BSP_TSQR_REGCAP", &Options::tsqr_regcap},
     {"tsqr_max_m", "BSP_TSQR_MAX_M", &Options::tsqr_max_m}, {"sb16_rows", "BSP_SB16_ROWS", &Options::sb16_rows},

@@ -52,6 +52,9 @@ struct Options {
     int tsqr_regcap = 1;         // BSP_TSQR_REGCAP: 1 = the 256-register variants of the tsqr.hip kernels (they fit beside one GEMM workgroup), 0 = uncapped
     int gemm_diag = 0;
     int bisect = 3, bisect_ept = 0;
+    int bisect_secant = 1;       // BSP_BISECT_SECANT: 1 = lock-step rounds take a safeguarded secant step where a bracket holds one eigenvalue
+                                 // (tridiag.hip; ~22 rounds instead of ~50); 0 = bisection only; >= 2: as 1, and the value is the
+                                 // fraction of a workgroup's 1024 eigenvalues (1 / value) left to the multisection tail (1 = 8)
     int bisect_tail = 1;         // BSP_BISECT_TAIL: 0 = lock-step bisection to the end (no multisection tail), for A/B timing
     int no_eigvec_prefetch = 0;
     int sb2sb_mfma = 1;          // 1: block-chasing item on the matrix cores (sbr2.hip); 0: the first, all-VALU kernel (cross-check)
