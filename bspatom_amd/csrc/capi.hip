@@ -78,7 +78,7 @@ const OptName OPT_TABLE[] = {
     {"poison_c", "BSP_POISON_C", &Options::poison_c}, {"sb2sb_mfma", "BSP_SB2SB_MFMA", &Options::sb2sb_mfma},
     {"ktime", "BSP_KTIME", &Options::ktime}, {"tsqr_regcap", "BSP_TSQR_REGCAP", &Options::tsqr_regcap},
     {"tsqr_max_m", "BSP_TSQR_MAX_M", &Options::tsqr_max_m}, {"sb16_rows", "BSP_SB16_ROWS", &Options::sb16_rows},
-    {"route", "BSP_ROUTE", &Options::route}, {"cw_onediv", "BSP_CW_ONEDIV", &Options::cw_onediv}, {"cw_items4", "BSP_CW_ITEMS4", &Options::cw_items4}, {"cw_nw", "BSP_CW_NW", &Options::cw_nw}, {"cw_ldspad", "BSP_CW_LDSPAD", &Options::cw_ldspad}, {"cw_ipw", "BSP_CW_IPW", &Options::cw_ipw}, {"cw_band8", "BSP_CW_BAND8", &Options::cw_band8}, {"cw_split", "BSP_CW_SPLIT", &Options::cw_split}, {"cw_diag", "BSP_CW_DIAG", &Options::cw_diag}, {"sb8_wgs", "BSP_SB8_WGS", &Options::sb8_wgs},
+    {"route", "BSP_ROUTE", &Options::route}, {"cw_onediv", "BSP_CW_ONEDIV", &Options::cw_onediv}, {"cw_items4", "BSP_CW_ITEMS4", &Options::cw_items4}, {"cw_nw", "BSP_CW_NW", &Options::cw_nw}, {"cw_ldspad", "BSP_CW_LDSPAD", &Options::cw_ldspad}, {"cw_ipw", "BSP_CW_IPW", &Options::cw_ipw}, {"cw_band8", "BSP_CW_BAND8", &Options::cw_band8}, {"cw_split", "BSP_CW_SPLIT", &Options::cw_split}, {"cw_diag", "BSP_CW_DIAG", &Options::cw_diag}, {"cw_streams", "BSP_CW_STREAMS", &Options::cw_streams}, {"sb8_wgs", "BSP_SB8_WGS", &Options::sb8_wgs},
     {"fused_probe", "BSP_FUSED_PROBE", &Options::fused_probe},
 };
 }  // namespace

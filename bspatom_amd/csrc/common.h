@@ -70,6 +70,7 @@ struct Options {
     int cw_items4 = 1;           // BSP_CW_ITEMS4: 1 = crawford_item4_kernel (four chase items per wave, an item per DPP row in the RQ loop),
                                  // 0 = crawford_item_kernel (one item per wave; the cross-check)
     int cw_nw = 1;               // BSP_CW_NW: waves per workgroup of crawford_item4_kernel (1 or 4; a wave never talks to another)
+    int cw_streams = 2;          // BSP_CW_STREAMS: the band reduction's channels in this many groups (1 .. 4), each on a stream of its own
     int cw_diag = 0;             // BSP_CW_DIAG: s_memtime stamps of the phases of crawford_item4_kernel's waves, averaged over a solve (stderr)
     int cw_split = 0;            // BSP_CW_SPLIT: > 0 = the band reduction runs from both ends of the pencil (n a multiple of 8); the value is the share
                                  // of the blocks, in percent, of the leading part (at most 50 = half the chase items).  NOT the default: the

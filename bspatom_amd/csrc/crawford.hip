@@ -32,6 +32,7 @@
 // prototype).  The band handed to the tridiagonalisation is stored in the original order again.
 #include "common.h"
 #include <cstdio>
+#include <mutex>
 
 namespace bsp {
 namespace {
@@ -887,7 +888,10 @@ int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const doubl
         BSP_HIP(hipMalloc(reinterpret_cast<void **>(&dg), 8 * sizeof(unsigned long long)));
         BSP_HIP(hipMemsetAsync(dg, 0, 8 * sizeof(unsigned long long), st));
     }
-    auto wavefront = [&](int t, int jlo, int nch, int jel, int cy) {
+    // c0, cy, ws: the channels c0 .. c0 + cy - 1 of the batch, on stream ws
+    auto wavefront = [&](int t, int jlo, int nch, int jel, int cy, int c0 = 0, hipStream_t ws = nullptr) {
+        if (!ws) ws = st;
+        double *gD = w.D + (size_t)c0 * Ns * CBB, *gE = w.E + (size_t)c0 * Ns * CBB, *gG = w.G + (size_t)c0 * Ns * CBB;
         const int items = nch + (jel ? 1 : 0);
         if (opts().cw_items4) {
             const int nw = opts().cw_nw == 4 ? 4 : 1;                      // waves per workgroup (A/B; a wave never talks to another)
@@ -896,24 +900,56 @@ int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const doubl
             const int ipw = (opts().cw_ipw == 1 || opts().cw_ipw == 2) ? opts().cw_ipw : 4;
             const int waves = (items + ipw - 1) / ipw;
             const dim3 grid((waves + nw - 1) / nw, cy), block(64 * nw);
-            if (opts().cw_onediv) hipLaunchKernelGGL((crawford_item4_kernel<true, 1>), dim3(waves, cy), dim3(64), 0, st, Ns, t, jlo, nch, jel, ipw, nl, qstride, nlead, w.Qel, w.D, w.E, w.G, dg);
-            else if (nw == 4) hipLaunchKernelGGL((crawford_item4_kernel<false, 4>), grid, block, 0, st, Ns, t, jlo, nch, jel, ipw, nl, qstride, nlead, w.Qel, w.D, w.E, w.G, dg);
-            else hipLaunchKernelGGL((crawford_item4_kernel<false, 1>), grid, block, (size_t)opts().cw_ldspad * 1024, st, Ns, t, jlo, nch, jel, ipw, nl, qstride, nlead, w.Qel, w.D, w.E, w.G, dg);
+            if (opts().cw_onediv) hipLaunchKernelGGL((crawford_item4_kernel<true, 1>), dim3(waves, cy), dim3(64), 0, ws, Ns, t, jlo, nch, jel, ipw, nl, qstride, nlead, w.Qel, gD, gE, gG, dg);
+            else if (nw == 4) hipLaunchKernelGGL((crawford_item4_kernel<false, 4>), grid, block, 0, ws, Ns, t, jlo, nch, jel, ipw, nl, qstride, nlead, w.Qel, gD, gE, gG, dg);
+            else hipLaunchKernelGGL((crawford_item4_kernel<false, 1>), grid, block, (size_t)opts().cw_ldspad * 1024, ws, Ns, t, jlo, nch, jel, ipw, nl, qstride, nlead, w.Qel, gD, gE, gG, dg);
         } else {
             const dim3 grid((items + 3) / 4, cy);
-            if (opts().cw_onediv) hipLaunchKernelGGL(crawford_item_kernel<true>, grid, dim3(256), 0, st, Ns, t, jlo, nch, jel, nl, qstride, nlead, w.Qel, w.D, w.E, w.G);
-            else hipLaunchKernelGGL(crawford_item_kernel<false>, grid, dim3(256), 0, st, Ns, t, jlo, nch, jel, nl, qstride, nlead, w.Qel, w.D, w.E, w.G);
+            if (opts().cw_onediv) hipLaunchKernelGGL(crawford_item_kernel<true>, grid, dim3(256), 0, ws, Ns, t, jlo, nch, jel, nl, qstride, nlead, w.Qel, gD, gE, gG);
+            else hipLaunchKernelGGL(crawford_item_kernel<false>, grid, dim3(256), 0, ws, Ns, t, jlo, nch, jel, nl, qstride, nlead, w.Qel, gD, gE, gG);
         }
     };
     // wavefront t: eliminations 2 j - 1 = t (1 <= j <= Nproc - 1), chase items 2 j + s = t with 0 <= s <= j - 2, j <= Nproc - 1
     const int tmax = (Nproc >= 3) ? 3 * Nproc - 5 : (Nproc == 2 ? 1 : 0);
+    // STREAMS (BSP_CW_STREAMS): the channels in groups, each group's launches on a stream of its own.  A launch of W waves takes
+    // ceil(W / 2048) rounds of the chip (2048 = two waves per SIMD) and a wave lives as long alone as in a full round, so a launch
+    // with 2050 .. 4096 waves -- two fifths of them at 128 channels -- leaves most of its second round empty; launches of another
+    // group, which depend on nothing in this one, fill it.  The items and their arithmetic are the same: the same bits.
+    int ngrp = 1;
+    if (!split && !dg && opts().cw_streams > 1) {
+        ngrp = opts().cw_streams > 4 ? 4 : opts().cw_streams;
+        while (ngrp > 1 && nl / ngrp < 16) --ngrp;
+    }
+    static hipStream_t s_aux[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t evf = nullptr, evj[3] = {nullptr, nullptr, nullptr};
+    if (ngrp > 1) {
+        static std::mutex mx;
+        std::lock_guard<std::mutex> lk(mx);
+        for (int g = 0; g < ngrp - 1; ++g)
+            if (!s_aux[g]) BSP_HIP(hipStreamCreateWithFlags(&s_aux[g], hipStreamNonBlocking));
+        BSP_HIP(hipEventCreateWithFlags(&evf, hipEventDisableTiming));
+        BSP_HIP(hipEventRecord(evf, st));
+        for (int g = 0; g < ngrp - 1; ++g) BSP_HIP(hipStreamWaitEvent(s_aux[g], evf, 0));
+    }
     for (int t = 1; t <= tmax; ++t) {
         const int jel = ((t & 1) && (t + 1) / 2 <= Nproc - 1) ? (t + 1) / 2 : 0;
         const int jlo = (t + 2 + 2) / 3;                                  // ceil((t + 2) / 3)
         const int jhi = (t / 2 < Nproc - 1) ? t / 2 : Nproc - 1;
         const int nch = (jhi >= jlo && jlo >= 2) ? jhi - jlo + 1 : 0;
         if (nch + (jel ? 1 : 0) == 0) continue;
-        wavefront(t, jlo, nch, jel, ny);
+        for (int g = 0; g < ngrp; ++g) {
+            const int c0 = (int)((long)ny * g / ngrp), c1 = (int)((long)ny * (g + 1) / ngrp);
+            wavefront(t, jlo, nch, jel, c1 - c0, c0, g == 0 ? st : s_aux[g - 1]);
+        }
+    }
+    if (ngrp > 1) {
+        for (int g = 0; g < ngrp - 1; ++g) {
+            BSP_HIP(hipEventCreateWithFlags(&evj[g], hipEventDisableTiming));
+            BSP_HIP(hipEventRecord(evj[g], s_aux[g]));
+            BSP_HIP(hipStreamWaitEvent(st, evj[g], 0));
+        }
+        hipEventDestroy(evf);                                              // released once the work recorded so far has passed them
+        for (int g = 0; g < ngrp - 1; ++g) hipEventDestroy(evj[g]);
     }
     if (split) {
         // the step at the cut, on the trailing parts (channels 0 .. nl - 1): elimination at block Nh, its fill chased to block 0

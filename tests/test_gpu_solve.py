@@ -695,13 +695,19 @@ def test_band_route_properties():
     note("band route vs dense route, 12 channels n=1024: normwise %.2e, worst relative %.2e" % (
         np.max(np.abs(E0 - Ed)) / lam, np.max(np.abs(E0 - Ed) / np.abs(Ed))))
     assert np.max(np.abs(E0 - Ed)) <= 1e-13 * lam
-    # ... and however many chase items a wave of the band reduction takes (chosen by launch size) or waves a workgroup has
+    # ... and however many chase items a wave of the band reduction takes, waves a workgroup has or streams its channels are spread over
     for kw in [dict(), dict(sb2st_ring=8), dict(sb2st_ring=4), dict(sb2st_ring=2), dict(sb2st_ring=1), dict(sb2st_force_abort=1),
-               dict(sb2st_force_abort=2), dict(cw_ipw=1), dict(cw_ipw=2), dict(cw_ipw=4), dict(cw_nw=4)]:
+               dict(sb2st_force_abort=2), dict(cw_ipw=1), dict(cw_ipw=2), dict(cw_ipw=4), dict(cw_nw=4), dict(cw_streams=1), dict(cw_streams=3)]:
         with _Options(**kw):
             E, info = prob.solve(0, 12)
         assert np.all(info == 0), kw
         assert np.array_equal(E, E0), (kw, np.max(np.abs(E - E0)) / lam)
+    # plain bisection instead of the secant rounds: both end in a bracket narrower than 2 eps |x| around the same eigenvalue of the same
+    # tridiagonal matrix -- every eigenvalue within a few ulp of ITSELF, the small ones included
+    with _Options(bisect_secant=0):
+        E, info = prob.solve(0, 12)
+    assert np.all(info == 0)
+    assert np.all(np.abs(E - E0) <= 8 * np.finfo(float).eps * np.abs(E0)), np.max(np.abs(E - E0) / np.abs(E0))
     with _Options(cw_items4=0):                                # the one-item-per-wave kernel: another summation order
         E, info = prob.solve(0, 12)
     assert np.all(info == 0) and np.max(np.abs(E - E0)) <= 1e-13 * lam
