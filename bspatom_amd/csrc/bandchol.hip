@@ -21,11 +21,14 @@ namespace bsp {
 // fixed trip count with masked addresses (3.8 -> ms at n = 4096: see the loop).
 // Workgroup g factors the band at SB + g * kn (kn = k n) into UB + g * kn, rdiag + g * n, rows 0 .. jstop - 1 only: the band route
 // run from both ends (crawford.hip) wants the leading half of the factor of S and of the index-reversed S, side by side.
+// BMAX = the largest half-width of the instance (8: every pencil of the band route; the sum over the previous rows has BMAX terms in
+// a dependent chain, masked down to b, so the narrow instance halves the longest chain of a column; same terms, same order)
+template <int BMAX>
 __global__ __launch_bounds__(64) void band_cholesky_kernel(int n, int k, int jstop, const double *__restrict__ SB0,
                                                           double *__restrict__ UB0,
                                                           double *__restrict__ rdiag0, int *info)
 {
-    constexpr int BMAX = 16, CH = 16, RING = 32;
+    constexpr int CH = 16, RING = 32;
     const double *SB = SB0 + (size_t)blockIdx.x * k * n;
     double *UB = UB0 + (size_t)blockIdx.x * k * n, *rdiag = rdiag0 + (size_t)blockIdx.x * n;
     __shared__ double ring[RING][BMAX + 1];       // ring[p & 31][d] = U(p, p+d) (rows j - b .. j - 1 are live: b <= 16 < 32)
@@ -186,7 +189,8 @@ int launch_band_cholesky(int n, int k, const double *d_SB, double *d_UB, double 
                          hipStream_t st)
 {
     if (k - 1 > 16 || k < 2) return BSP_ERR_ARG;
-    hipLaunchKernelGGL(band_cholesky_kernel, dim3(1), dim3(64), 0, st, n, k, n, d_SB, d_UB, d_rdiag, d_info);
+    if (k - 1 <= 8) hipLaunchKernelGGL(band_cholesky_kernel<8>, dim3(1), dim3(64), 0, st, n, k, n, d_SB, d_UB, d_rdiag, d_info);
+    else hipLaunchKernelGGL(band_cholesky_kernel<16>, dim3(1), dim3(64), 0, st, n, k, n, d_SB, d_UB, d_rdiag, d_info);
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }
@@ -195,7 +199,8 @@ int launch_band_cholesky(int n, int k, const double *d_SB, double *d_UB, double 
 int launch_band_cholesky_pair(int n, int k, int jstop, const double *d_SB, double *d_UB, double *d_rdiag, int *d_info, hipStream_t st)
 {
     if (k - 1 > 16 || k < 2 || jstop < 1 || jstop > n) return BSP_ERR_ARG;
-    hipLaunchKernelGGL(band_cholesky_kernel, dim3(2), dim3(64), 0, st, n, k, jstop, d_SB, d_UB, d_rdiag, d_info);
+    if (k - 1 <= 8) hipLaunchKernelGGL(band_cholesky_kernel<8>, dim3(2), dim3(64), 0, st, n, k, jstop, d_SB, d_UB, d_rdiag, d_info);
+    else hipLaunchKernelGGL(band_cholesky_kernel<16>, dim3(2), dim3(64), 0, st, n, k, jstop, d_SB, d_UB, d_rdiag, d_info);
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }
