@@ -368,12 +368,13 @@ def flop_band(n):
     chase items (N-1)(N-2)/2 with N = ceil(n/8), each the RQ of an 8 x 16 block (2*16*64 - 2/3*512), its 16 x 16 factor formed
     (8 reflectors x 4*256), the congruence Q^T (W Q) (2 products of 2*16^3) and Q^T [E; 0] (2*16*8*8); N - 1 eliminations (the two
     products and the two small ones); band of half-width 8 -> tridiagonal: 6 n^2 8; bisection: 54 Sturm counts of n rows for n
-    eigenvalues, 3 fp64 operations per row."""
+    eigenvalues, 3 fp64 operations per row -- until round 4's secant rounds: now 32 evaluation rounds of a workgroup's 1024 slots
+    (the first-level grid, ~24 lock-step rounds, 6 - 9 rounds of the multisection tail)."""
     N = (n + 7) // 8
     item = (2 * 16 * 64 - 2.0 / 3.0 * 512) + 8 * 4 * 256 + 2 * 2 * 16 ** 3 + 2 * 16 * 8 * 8
     elim = 2 * 2 * 16 ** 3 + 2 * 2 * 16 * 8 * 8
     return {"band_reduction": (N - 1) * (N - 2) / 2.0 * item + (N - 1) * elim, "band_chase": 6.0 * n * n * 8,
-            "bisect": 54.0 * 3.0 * n * n}
+            "bisect": 32.0 * 3.0 * n * n}
 
 
 def dense_kernel_entries(ktimes, npad, nl, pmc_bytes, pmc_file, pmc_stale, mfma, mfma_file, mfma_stale):
@@ -516,18 +517,23 @@ def report(args, world, n, npad, main, ktimes, kstage, route):
         if calls:
             ach = fb["band_reduction"] * nl / (ms_sum * 1e-3) / 1e12
             items = (N - 1) * (N - 2) // 2
+            grp = max(1, min(int(capi.get_option("cw_streams")), 4))          # channel groups, each on a stream of its own
+            while grp > 1 and nl // grp < 16:
+                grp -= 1
             kern.append({"kernel": "crawford_item4_kernel (+ its set-up kernels; crawford_item_kernel with BSP_CW_ITEMS4=0; csrc/crawford.hip)", "what": "banded pencil -> band of half-width 8: "
-                         "%d chase items of 8 x 8 blocks per channel in %d wavefront launches" % (items, 3 * N - 5), "bound": "mfma",
-                         "launches_per_step": 3 * N - 5 + 5, "kernel_ms_per_step": ms_sum, "avg_launch_ms": ms_sum / (3 * N),
+                         "%d chase items of 8 x 8 blocks per channel in %d wavefronts = %d launches (the channels in %d groups, each on a stream of its own)"
+                         % (items, 3 * N - 5, (3 * N - 5) * grp, grp), "bound": "mfma",
+                         "launches_per_step": (3 * N - 5) * grp + 6, "kernel_ms_per_step": ms_sum, "avg_launch_ms": ms_sum / ((3 * N - 5) * grp),
+                         "avg_launch_ms_definition": "the stage's time / its launches; the groups' launches overlap, a launch alone takes ~2 x this",
                          "launch_ms_source": "HIP events around the whole stage, one extra untimed step of this run (bspatom_kernel_times)",
                          "flop_per_step": fb["band_reduction"] * nl, "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_PEAK_TFLOPS, "bytes_model_per_step": items * 11 * 512.0 * nl,
                          "bytes_model_definition": "11 blocks of 512 B read or written per item (mostly L2 / Infinity Cache hits: the working "
                                                    "set of a channel is 0.8 MB)",
                          "traffic": pmc_bytes("crawford_item"), "traffic_source": pmc_file, "traffic_stale": pmc_stale,
-                         "limited_by": "issue and latency at two waves per SIMD (250 registers): ~640 instructions per item, the serial sqrt / "
-                                       "division chain of eight reflectors, 12 fp64 MFMAs (on gfx950 an fp64 MFMA costs what its 1024 "
-                                       "multiply-adds cost on the vector pipe); wavefront launches quantise the occupancy"})
+                         "limited_by": "the life of ONE wave of four items (23 500 cycles: eight dependent reflector steps, 48 fp64 MFMAs at 64 cycles) "
+                                       "times the rounds of waves a wavefront launch needs: a launch has 2750 waves on average and the chip "
+                                       "holds 2048 (two per SIMD, 250 registers); DESIGN.md 4.5, profiles/r04_experiments.txt 14 - 16"})
         ms_sum, calls = kt("sbr_rows")
         # tiles of 8: a pass of 16 sweeps streams the remaining band (window columns of 16 rows) in and out once
         b2 = sum(2 * 16 * 8 * (n - s0_) for s0_ in range(0, n - 2, 16)) * nl
@@ -545,7 +551,8 @@ def report(args, world, n, npad, main, ktimes, kstage, route):
             kern.append({"kernel": "bisect3_kernel", "bound": "mfma", "launches_per_step": calls, "avg_launch_ms": ms_sum / calls,
                          "kernel_ms_per_step": ms_sum, "launch_ms_source": src_live, "flop_per_step": fb["bisect"] * nl, "achieved": ach,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
-                         "limited_by": "fp64 vector pipe: 3 fp64 + ~1.7 other instructions per row and eigenvalue (DESIGN 4.3)"})
+                         "limited_by": "fp64 vector pipe: 3 fp64 + ~1.6 other instructions per row and eigenvalue; ~19 evaluations per eigenvalue, "
+                                       "~32 rounds per workgroup in lock step (DESIGN 4.3)"})
         F = sum(fb.values())
         ach = F * main["value"] / 1e12
         ceiling = FP64_PEAK_TFLOPS * 1e12 * world / flop_dense(n, args.k)
