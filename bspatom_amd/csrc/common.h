@@ -71,6 +71,8 @@ struct Options {
                                  // 0 = crawford_item_kernel (one item per wave; the cross-check)
     int cw_nw = 1;               // BSP_CW_NW: waves per workgroup of crawford_item4_kernel (1 or 4; a wave never talks to another)
     int cw_streams = 2;          // BSP_CW_STREAMS: the band reduction's channels in this many groups (1 .. 4), each on a stream of its own
+    int s_overlap = 1;           // BSP_S_OVERLAP: band route: the S-only part of the reduction (band Cholesky ..) on a stream of its own beside the
+                                 // assembly of the H_l
     int cw_diag = 0;             // BSP_CW_DIAG: s_memtime stamps of the phases of crawford_item4_kernel's waves, averaged over a solve (stderr)
     int cw_split = 0;            // BSP_CW_SPLIT: > 0 = the band reduction runs from both ends of the pencil (n a multiple of 8); the value is the share
                                  // of the blocks, in percent, of the leading part (at most 50 = half the chase items).  NOT the default: the
@@ -170,8 +172,9 @@ struct CrawfordWork {
 bool crawford_supported(int n, int k);
 size_t crawford_work_bytes(int n, int k, int nl);
 void crawford_carve(void *base, int n, int k, int nl, CrawfordWork *w);
+int crawford_prepare(int n, int k, const double *d_SB, const CrawfordWork &w, hipStream_t st);   // the S-only part (run: unless s_prepared)
 int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const double *d_HB, const CrawfordWork &w, double *d_AB,
-                 hipStream_t st);
+                 hipStream_t st, bool s_prepared = false);
 // sy2sb.hip
 // tsqr.hip: panel factorisation on many workgroups (TSQR + Householder reconstruction), BSP_PANEL_QR=3
 long tsqr_scr_doubles(int npad);
@@ -236,6 +239,6 @@ struct PipeBufs {
 int pipeline_route(int n, int k);
 size_t pipe_bytes_per_channel(int npad);
 int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const double *d_HB,
-                     const PipeBufs &b, double *d_Eout, hipStream_t st, hipEvent_t *ev, bool with_bisect = true);
+                     const PipeBufs &b, double *d_Eout, hipStream_t st, hipEvent_t *ev, bool with_bisect = true, bool s_prepared = false);
 
 }  // namespace bsp

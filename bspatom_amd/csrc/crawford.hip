@@ -329,29 +329,23 @@ __device__ __forceinline__ void rq4_step(double (&x)[16], double (&q)[16], doubl
     }
 }
 
-template <bool ONEDIV, int NW>
-__global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, int t, int jlo, int nch, int jel, int ipw, int nlh, int qstride,
-                                                            int nlead, const double *__restrict__ Qel, double *Dall, double *Eall, double *Gall,
-                                                            unsigned long long *diag)
+// The work of one wave on its (up to) four items of wavefront t of channel `chan`: items idx0 .. idx0 + ipw - 1 of the wavefront's
+// list (nch chase items j = jlo .., then the elimination jel if any).  Qsw / Bcw: the wave's LDS (4 x 16 x QLD and 4 x 16 doubles).
+template <bool ONEDIV>
+__device__ __forceinline__ void cw_quad(const int N, const int t, const int jlo, int nch, int jel, const int ipw, const int nlh,
+                                        const int qstride, const int nlead, const int chan, const int idx0, const int lane,
+                                        double *Qsw, double *Bcw, const double *__restrict__ Qel, double *Dall, double *Eall,
+                                        double *Gall, unsigned long long *diag)
 {
-    // BSP_CW_DIAG: s_memtime stamps of a wave's phases, summed over the waves of every launch (diag[0..6] ticks, diag[7] waves)
     unsigned long long ts0 = 0, tsa = 0, tsb = 0, tsc = 0, tsd = 0, tse = 0;
-    if (diag && (((blockIdx.x & 7) | (blockIdx.y & 7)) != 0)) diag = nullptr;   // one wave in 64 reports (the sums are atomics)
     if (diag) ts0 = __builtin_amdgcn_s_memtime();
-    if ((int)blockIdx.y >= nlh) {                                          // a leading part of nlead blocks: the items beyond do not exist
+    if (chan >= nlh) {                                                     // a leading part of nlead blocks: the items beyond do not exist
         if (jlo + nch > nlead) nch = nlead > jlo ? nlead - jlo : 0;
         if (jel >= nlead) jel = 0;
     }
-    __shared__ __attribute__((aligned(16))) double Qs[NW][4][16 * QLD];  // per wave and item slot: Q, row-major, stride QLD
-    __shared__ __attribute__((aligned(16))) double Bc[NW][4][16];        // per wave and item slot: the row that goes round
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // ipw = items per wave: 4; 2 or 1 only as an experiment (BSP_CW_IPW).  An item's arithmetic does not depend on the slot it
-    // sits in: the choice changes no bit (tests/test_gpu_solve.py::test_band_route_properties).
-    const int idx0 = (blockIdx.x * NW + wave) * ipw;                     // first of this wave's items
     const int items = nch + (jel > 0 ? 1 : 0);
     if (idx0 >= items) return;
-    const size_t chn = (size_t)blockIdx.y * N * CBB;
+    const size_t chn = (size_t)chan * N * CBB;
     double *D = Dall + chn, *E = Eall + chn, *G = Gall + chn;
 
     // ---- phase A: the RQ loops of the wave's chase items, an item per DPP row ----
@@ -372,7 +366,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
         }
 #pragma unroll
         for (int c = 0; c < 16; ++c) q[c] = (c == r) ? 1.0 : 0.0;
-        double *bc = &Bc[wave][it][0];
+        double *bc = Bcw + it * 16;
         if (diag) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tsa = __builtin_amdgcn_s_memtime(); }   // X has arrived
         rq4_step<7, ONEDIV>(x, q, bc, r);
         rq4_step<6, ONEDIV>(x, q, bc, r);
@@ -388,7 +382,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
 #pragma unroll
             for (int c = 0; c < CB; c += 2) *reinterpret_cast<double2 *>(ep + c) = make_double2(x[CB + c], x[CB + c + 1]);
         }
-        double *qs = &Qs[wave][it][r * QLD];
+        double *qs = Qsw + it * (16 * QLD) + r * QLD;
 #pragma unroll
         for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2 *>(qs + c) = make_double2(q[c], q[c + 1]);
     }
@@ -439,7 +433,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
     for (int s = 0; s < 4; ++s) if (kind[s] == 2) se = s;
     const bool has_x = se >= 0 && (jel + 1 <= N - 1);
     if (se >= 0) {
-        const double *Qj = Qel + ((int)blockIdx.y >= nlh ? qstride : 0) + (size_t)jel * 256;
+        const double *Qj = Qel + ((int)chan >= nlh ? qstride : 0) + (size_t)jel * 256;
 #pragma unroll
         for (int r = 0; r < 4; ++r) qe[r] = Qj[(4 * r + g) * 16 + c];
         const double *Ej = E + (size_t)(has_x ? jel : 0) * CBB;
@@ -458,7 +452,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
         double *D0 = D + (size_t)p * CBB, *D1 = D0 + CBB, *E0 = E + (size_t)p * CBB;
         double q[4];
         if (!elim) {
-            const double *qs = &Qs[wave][s][0];
+            const double *qs = Qsw + s * (16 * QLD);
 #pragma unroll
             for (int r = 0; r < 4; ++r) q[r] = qs[(4 * r + g) * QLD + c];
         } else {
@@ -518,6 +512,23 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
             atomicAdd(diag + 7, 1ull);
         }
     }
+}
+
+template <bool ONEDIV, int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, int t, int jlo, int nch, int jel, int ipw, int nlh, int qstride,
+                                                            int nlead, const double *__restrict__ Qel, double *Dall, double *Eall, double *Gall,
+                                                            unsigned long long *diag)
+{
+    // BSP_CW_DIAG: s_memtime stamps of a wave's phases, summed over the waves of every launch (diag[0..6] ticks, diag[7] waves)
+    if (diag && (((blockIdx.x & 7) | (blockIdx.y & 7)) != 0)) diag = nullptr;   // one wave in 64 reports (the sums are atomics)
+    __shared__ __attribute__((aligned(16))) double Qs[NW][4][16 * QLD];  // per wave and item slot: Q, row-major, stride QLD
+    __shared__ __attribute__((aligned(16))) double Bc[NW][4][16];        // per wave and item slot: the row that goes round
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // ipw = items per wave: 4; 2 or 1 only as an experiment (BSP_CW_IPW).  An item's arithmetic does not depend on the slot it
+    // sits in: the choice changes no bit (tests/test_gpu_solve.py::test_band_route_properties).
+    cw_quad<ONEDIV>(N, t, jlo, nch, jel, ipw, nlh, qstride, nlead, (int)blockIdx.y, (blockIdx.x * NW + wave) * ipw, lane, &Qs[wave][0][0],
+                    &Bc[wave][0][0], Qel, Dall, Eall, Gall, diag);
 }
 
 // index-reversed overlap band: SBf[d][i] = S_f(i, i + d) = S(n-1-i-d, n-1-i)
@@ -852,8 +863,48 @@ bool crawford_supported(int n, int k) { return k >= 2 && k - 1 <= CB && n >= 2 *
 // w.info (device) receives the order of the minor of the REVERSED overlap at which its Cholesky factorisation broke down, or 0
 // (run from both ends: nonzero if one of the three factorisations broke down -- the caller finds DSYGV's own info with the
 // forward factorisation).
+namespace {
+struct CwShape { int N, Nl, Nh, Nproc, Ns; bool split; };
+CwShape cw_shape(int n)
+{
+    CwShape c;
+    c.N = (n + CB - 1) / CB;
+    // from both ends: both parts whole blocks and long enough to have a chase.  BSP_CW_SPLIT = the share of the blocks, in percent,
+    // that the LEADING part takes (at most half): its fill is chased towards r = 0, which is what costs accuracy (ORIENTATION).
+    c.Nl = (opts().cw_split > 0 && n % CB == 0) ? (int)((long)c.N * (opts().cw_split > 50 ? 50 : opts().cw_split) / 100) : 0;
+    c.split = c.Nl >= 3 && c.N - c.Nl >= 4;
+    if (!c.split) c.Nl = 0;
+    c.Nh = c.split ? c.N - c.Nl : 0;                                       // blocks of the trailing part (the longer one)
+    c.Nproc = c.split ? c.Nh : c.N;                                        // blocks of the longest process
+    c.Ns = c.split ? c.Nh + 2 : c.N;                                       // block slots of a channel of the batch
+    return c;
+}
+}  // namespace
+
+// The part of the reduction that depends on S alone: the reversed band, its factor, the elimination transforms (the same for every
+// channel).  On its own so that the caller can run it on a stream of its own beside the assembly of the H_l, as soon as S is there.
+int crawford_prepare(int n, int k, const double *d_SB, const CrawfordWork &w, hipStream_t st)
+{
+    if (!crawford_supported(n, k)) return BSP_ERR_UNSUPPORTED;
+    const CwShape c = cw_shape(n);
+    const int N = c.N, Nh = c.Nh, Nl = c.Nl;
+    int rc;
+    BSP_HIP(hipMemsetAsync(w.info, 0, sizeof(int), st));
+    hipLaunchKernelGGL(crawford_flip_kernel, dim3((n * k + 255) / 256), dim3(256), 0, st, n, k, d_SB, w.SBf);
+    if (c.split) {
+        if ((rc = launch_band_cholesky_pair(n, k, CB * Nh, w.SBf, w.UBf, w.rdiagf, w.info, st))) return rc;
+        hipLaunchKernelGGL(crawford_setup_kernel, dim3(Nh, 2), dim3(64), 0, st, n, k, N, w.UBf, w.LiB, w.Qel);
+        hipLaunchKernelGGL(crawford_cut_setup_kernel, dim3(1), dim3(64), 0, st, n, k, N, Nh, Nl, w.SBf, w.LiB, w.Qel, w.info);
+    } else {
+        if ((rc = launch_band_cholesky(n, k, w.SBf, w.UBf, w.rdiagf, w.info, st))) return rc;
+        hipLaunchKernelGGL(crawford_setup_kernel, dim3(N, 1), dim3(64), 0, st, n, k, N, w.UBf, w.LiB, w.Qel);
+    }
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
+
 int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const double *d_HB, const CrawfordWork &w, double *d_AB,
-                 hipStream_t st)
+                 hipStream_t st, bool s_prepared)
 {
     if (!crawford_supported(n, k)) return BSP_ERR_UNSUPPORTED;
     const int N = (n + CB - 1) / CB;
@@ -869,16 +920,7 @@ int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const doubl
     const int nlead = split ? Nl : 0x7fffffff;
     int rc;
     KScope kt(KS_CRAWFORD, st);
-    BSP_HIP(hipMemsetAsync(w.info, 0, sizeof(int), st));
-    hipLaunchKernelGGL(crawford_flip_kernel, dim3((n * k + 255) / 256), dim3(256), 0, st, n, k, d_SB, w.SBf);
-    if (split) {
-        if ((rc = launch_band_cholesky_pair(n, k, CB * Nh, w.SBf, w.UBf, w.rdiagf, w.info, st))) return rc;
-        hipLaunchKernelGGL(crawford_setup_kernel, dim3(Nh, 2), dim3(64), 0, st, n, k, N, w.UBf, w.LiB, w.Qel);
-        hipLaunchKernelGGL(crawford_cut_setup_kernel, dim3(1), dim3(64), 0, st, n, k, N, Nh, Nl, w.SBf, w.LiB, w.Qel, w.info);
-    } else {
-        if ((rc = launch_band_cholesky(n, k, w.SBf, w.UBf, w.rdiagf, w.info, st))) return rc;
-        hipLaunchKernelGGL(crawford_setup_kernel, dim3(N, 1), dim3(64), 0, st, n, k, N, w.UBf, w.LiB, w.Qel);
-    }
+    if (!s_prepared && (rc = crawford_prepare(n, k, d_SB, w, st))) return rc;
     hipLaunchKernelGGL(crawford_init_kernel, dim3(Nproc, ny), dim3(64), 0, st, n, k, Ns, nl, N * CBB, d_HB, w.LiB, w.D, w.E);
     BSP_HIP(hipGetLastError());
     const int qstride = N * 256;
