@@ -1101,7 +1101,8 @@ __device__ __forceinline__ void stores_done_barrier()
     else asm volatile("s_waitcnt lgkmcnt(7)\n\ts_barrier" ::: "memory");
 }
 
-template <int B>
+// DIAG: the instrumented instance (BSP_SB2ST_DIAG; `diag` non-null); the other carries no stamp, no test for one
+template <int B, bool DIAG = false>
 __global__ __launch_bounds__(SB16R_THREADS) void sbr_rows_kernel(int n, int npad, int batch, double *__restrict__ ABall,
                                                                  double *__restrict__ dall, double *__restrict__ eall,
                                                                  long long *diag, Sb16Ctl *ctl, int P, int *status, int force_abort)
@@ -1195,11 +1196,11 @@ __global__ __launch_bounds__(SB16R_THREADS) void sbr_rows_kernel(int n, int npad
                 SB16R_RPN(t + PH) \
                 { int r4 = s0 + NSW + B * ((t + PH - MLAG) - LAG * (NSW - 1) - 1);      /* RPn of MLAG steps ago */ \
                   RPold = r4 > n ? n : (r4 < s0 ? s0 : r4); } \
-                mover_step<B, PH>(Lw, AB, n, npad, LP + B * PH, RP, RPn, RPold, ps, lane, pollp, pubp, pw, ptmp, C, status, diag != nullptr, dacc); \
-                if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime(); \
+                mover_step<B, PH>(Lw, AB, n, npad, LP + B * PH, RP, RPn, RPold, ps, lane, pollp, pubp, pw, ptmp, C, status, DIAG, dacc); \
+                if (DIAG) dt0 = (long long)__builtin_amdgcn_s_memtime(); \
                 RP = RPn; \
                 lds_only_barrier(); \
-                if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; } \
+                if (DIAG) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; } \
             }
             for (int t = 0; t < nsteps; t += 4) {
                 SB16R_MSTEP(0) SB16R_MSTEP(1) SB16R_MSTEP(2) SB16R_MSTEP(3)
@@ -1230,9 +1231,7 @@ __global__ __launch_bounds__(SB16R_THREADS) void sbr_rows_kernel(int n, int npad
                 }
                 __syncthreads();
                 for (int t = 0; t < nsteps; ++t) {
-                    SB16R_RPN(t)
-                    RP = RPn;
-                    if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime();
+                    if (DIAG) dt0 = (long long)__builtin_amdgcn_s_memtime();
                     const int k4 = t - LAG * sw, r04 = s4 + 1 + B * k4;   // item g of the wave: sweep s0 + sw, item t - 3 sw
                     const bool act = k4 >= 0 && live && r04 < n, actN = k4 >= -1 && live && r04 + B < n;
                     const int xw = xs0 + (((t + 1) & 1) << 8);
@@ -1254,10 +1253,10 @@ __global__ __launch_bounds__(SB16R_THREADS) void sbr_rows_kernel(int n, int npad
 #pragma unroll
                         for (int i = 0; i < B; ++i) bt[i] = Lw[at[i] + (WR - 1) * i];
                     }
-                    if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[2] += t_ - dt0; dt0 = t_; }
+                    if (DIAG) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[2] += t_ - dt0; dt0 = t_; }
                     if (__builtin_amdgcn_ballot_w64(actN) != 0) stores_done_barrier<B>();
                     else lds_only_barrier();
-                    if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; }
+                    if (DIAG) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; }
                 }
             } else if (role == 1) {
                 double d[B];
@@ -1270,9 +1269,7 @@ __global__ __launch_bounds__(SB16R_THREADS) void sbr_rows_kernel(int n, int npad
                 }
                 __syncthreads();
                 for (int t = 0; t < nsteps; ++t) {
-                    SB16R_RPN(t)
-                    RP = RPn;
-                    if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime();
+                    if (DIAG) dt0 = (long long)__builtin_amdgcn_s_memtime();
                     const int k4 = t - LAG * sw, r04 = s4 + 1 + B * k4;
                     const bool act = k4 >= 0 && live && r04 < n, actN = k4 >= -1 && live && r04 + B < n;
                     if (act) chase4_diag<B>(Lw, d, ad, j, xs0 + ((t & 1) << 8), zi, dumpi);
@@ -1283,27 +1280,29 @@ __global__ __launch_bounds__(SB16R_THREADS) void sbr_rows_kernel(int n, int npad
 #pragma unroll
                         for (int i = 0; i < B; ++i) d[i] = Lw[ad[i]];
                     }
-                    if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[2] += t_ - dt0; dt0 = t_; }
+                    if (DIAG) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[2] += t_ - dt0; dt0 = t_; }
                     if (__builtin_amdgcn_ballot_w64(actN) != 0) stores_done_barrier<B>();
                     else lds_only_barrier();
-                    if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; }
+                    if (DIAG) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; }
                 }
             } else {
                 __syncthreads();
                 for (int t = 0; t < nsteps; ++t) {
-                    SB16R_RPN(t)
-                    RP = RPn;
-                    if (diag) dt0 = (long long)__builtin_amdgcn_s_memtime();
+                    if (DIAG) dt0 = (long long)__builtin_amdgcn_s_memtime();
                     const int k4 = t - LAG * sw, r04 = s4 + 1 + B * k4;
                     if (k4 > 0 && live && r04 < n) chase4_bulge<B>(Lw, r04, r04 - B, j, xs0 + ((t & 1) << 8), dumpi);
-                    if (diag) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[2] += t_ - dt0; dt0 = t_; }
+                    if (DIAG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[2] += t_ - dt0; dt0 = t_; }
                     lds_only_barrier();
-                    if (diag) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; }
+                    if (DIAG) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[3] += t_ - dt0; dacc[4] += 1; }
                 }
             }
         }
-#undef SB16R_RPN
+        if (wv != NCW4 && nsteps > 0) {                   // the chasing waves do not track RP step by step: its value after the last one
+            SB16R_RPN(nsteps - 1)
+            RP = RPn;
+        }
         LP += 4 * B * ((nsteps + 3) / 4);                 // what was requested (far beyond n by the end of a pass)
+#undef SB16R_RPN
         __syncthreads();
         int hi = LP < n ? LP : n;
         for (int idx = tid; idx < (hi - RP) * WR; idx += SB16R_THREADS) {
@@ -1314,7 +1313,7 @@ __global__ __launch_bounds__(SB16R_THREADS) void sbr_rows_kernel(int n, int npad
         if (pubp && tid == 0)
             __hip_atomic_store(pubp, ((unsigned long long)ps << 32) + (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (diag && blockIdx.x == 0 && lane == 0)
+    if (DIAG && blockIdx.x == 0 && lane == 0)
         for (int q = 0; q < 5; ++q) diag[wv * 5 + q] = dacc[q];
     if (stride > 1 && (npass - 1) % stride != w && npass > 0) return;   // the member of the last pass has seen every pass end
     __syncthreads();
@@ -1374,12 +1373,16 @@ int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double 
     if (!attr) {
         BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sb16st_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     SB16_LDS));
-        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sbr_rows_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sbr_rows_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     Rw<16>::LDS));
-        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sbr_rows_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sbr_rows_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    Rw<8>::LDS));
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sbr_rows_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    Rw<16>::LDS));
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sbr_rows_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     Rw<8>::LDS));
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(sbr_rows_kernel<8>), SB16R_THREADS,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(sbr_rows_kernel<8, false>), SB16R_THREADS,
                                                          Rw<8>::LDS) == hipSuccess && nb >= 1) wg8 = nb > 2 ? 2 : nb;
         attr = true;
     }
@@ -1428,11 +1431,17 @@ int launch_sb16st(int n, int npad, int batch, double *d_AB, double *d_d, double 
     const int fab = opts().sb2st_force_abort;
     auto launch = [&](long long *dbuf) {
         if (rows) hipLaunchKernelGGL(band_tail_zero_kernel, dim3(batch), dim3(256), 0, st, n, npad, 2 * hb, d_AB);
-        if (hb == 8)
-            hipLaunchKernelGGL(sbr_rows_kernel<8>, dim3(nblk), dim3(SB16R_THREADS), Rw<8>::LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf,
+        if (hb == 8 && dbuf)
+            hipLaunchKernelGGL((sbr_rows_kernel<8, true>), dim3(nblk), dim3(SB16R_THREADS), Rw<8>::LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf,
+                               d_ctl, P, d_status, fab);
+        else if (hb == 8)
+            hipLaunchKernelGGL((sbr_rows_kernel<8, false>), dim3(nblk), dim3(SB16R_THREADS), Rw<8>::LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf,
+                               d_ctl, P, d_status, fab);
+        else if (rows && dbuf)
+            hipLaunchKernelGGL((sbr_rows_kernel<16, true>), dim3(nblk), dim3(SB16R_THREADS), Rw<16>::LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf,
                                d_ctl, P, d_status, fab);
         else if (rows)
-            hipLaunchKernelGGL(sbr_rows_kernel<16>, dim3(nblk), dim3(SB16R_THREADS), Rw<16>::LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf,
+            hipLaunchKernelGGL((sbr_rows_kernel<16, false>), dim3(nblk), dim3(SB16R_THREADS), Rw<16>::LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf,
                                d_ctl, P, d_status, fab);
         else
             hipLaunchKernelGGL(sb16st_kernel, dim3(nblk), dim3(576), SB16_LDS, st, n, npad, batch, d_AB, d_d, d_e, dbuf, d_ctl, P,

@@ -588,8 +588,8 @@ def test_no_scratch_in_the_kernels_of_the_default_route():
         "sb2st_kernel_v7<1>": 40,       # the instrumented instance of BSP_SB2ST_DIAG
     }
     band_route = ["point_table_kernel", "band_kernel", "crawford_item_kernel", "crawford_setup_kernel", "crawford_init_kernel",
-                  "crawford_band_kernel", "crawford_corner_kernel", "crawford_flip_kernel", "band_cholesky_kernel", "sbr_rows_kernel<8>",
-                  "sbr_rows_kernel<16>", "band_tail_zero_kernel",
+                  "crawford_band_kernel", "crawford_corner_kernel", "crawford_flip_kernel", "band_cholesky_kernel", "sbr_rows_kernel<8, false>",
+                  "sbr_rows_kernel<16, false>", "band_tail_zero_kernel",
                   "bisect3_kernel", "bisect_one3_kernel", "invit_kernel", "wf_kernel"]
     seen = {b: 0 for b in band_route}
     bad = []
