@@ -334,7 +334,7 @@ __device__ __forceinline__ void rq4_step(double (&x)[16], double (&q)[16], doubl
 template <bool ONEDIV>
 __device__ __forceinline__ void cw_quad(const int N, const int t, const int jlo, int nch, int jel, const int ipw, const int nlh,
                                         const int qstride, const int nlead, const int chan, const int idx0, const int lane,
-                                        double *Qsw, double *Bcw, const double *__restrict__ Qel, double *Dall, double *Eall,
+                                        double *Qsw, double *Bcw, double *Wsw, const double *__restrict__ Qel, double *Dall, double *Eall,
                                         double *Gall, unsigned long long *diag)
 {
     unsigned long long ts0 = 0, tsa = 0, tsb = 0, tsc = 0, tsd = 0, tse = 0;
@@ -347,6 +347,25 @@ __device__ __forceinline__ void cw_quad(const int N, const int t, const int jlo,
     if (idx0 >= items) return;
     const size_t chn = (size_t)chan * N * CBB;
     double *D = Dall + chn, *E = Eall + chn, *G = Gall + chn;
+
+    // ---- the operands of phase B, requested now by LDS-DMA (no registers: they land in Wsw while phase A computes; none of them is
+    // written by phase A, which only stores E_{p+1}).  Per item two instructions of 1 KB: D_p and D_{p+1} are neighbours in memory,
+    // E_p goes with the block in front of the window, E_{p-1} (E_p again where there is none). ----
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int idx = idx0 + s;
+        const int kd = s >= ipw ? 0 : (idx < nch ? 1 : ((idx == nch && jel > 0) ? 2 : 0));
+        if (kd != 0) {                                                   // uniform
+            const int jx = kd == 1 ? jlo + idx : jel, p = kd == 2 ? jel - 1 : jx - 2 - (t - 2 * jx);
+            const double *srcD = D + (size_t)p * CBB + 2 * lane;
+            const double *srcE = E + (size_t)((lane < 32 || p < 1) ? p : p - 1) * CBB + 2 * (lane & 31);
+            // written as assembly: through the builtin the compiler waits for the DMA (vmcnt(0)) before the wave's next LDS operation
+            const unsigned ldsD = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(Wsw + s * 4 * CBB);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+                         "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                         :: "v"(srcD), "v"(srcE), "s"(ldsD), "s"(ldsD + 2 * CBB * 8) : "memory", "m0");
+        }
+    }
 
     // ---- phase A: the RQ loops of the wave's chase items, an item per DPP row ----
     if (idx0 < nch) {
@@ -386,7 +405,11 @@ __device__ __forceinline__ void cw_quad(const int N, const int t, const int jlo,
 #pragma unroll
         for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2 *>(qs + c) = make_double2(q[c], q[c + 1]);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this wave's own LDS stores (no other wave reads them)
+    // this wave's own LDS stores (no other wave reads them) and the DMA of phase B's operands, requested a phase ago: the counter is
+    // in order over loads and stores, and the only operations younger than the DMA are the four 16-byte stores of R that a wave with
+    // a chase item has just issued (lanes 0 .. 7 of its first item are always live)
+    if (idx0 < nch) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     // Everything phase B computes from the kernel's arguments (item numbers, block addresses of four items) would otherwise be
     // hoisted in front of phase A and sit in registers across it (96 dwords spilled at three waves per SIMD): the two values it
     // all derives from are redefined here, as far as the compiler can tell.
@@ -411,20 +434,15 @@ __device__ __forceinline__ void cw_quad(const int N, const int t, const int jlo,
         pp[s] = kind[s] == 2 ? jel - 1 : jj[s] - 2 - (t - 2 * jj[s]);
         if (kind[s] == 0) { jj[s] = jj[0]; pp[s] = pp[0]; }
         const int p = pp[s];
-        const double *D0 = D + (size_t)p * CBB, *D1 = D0 + CBB, *E0 = E + (size_t)p * CBB;
+        const double *W0 = Wsw + s * 4 * CBB, *W1 = W0 + CBB, *WE = W0 + 2 * CBB, *WM = W0 + 3 * CBB;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int R = 4 * r + g;
             const int hi = R > c8 ? R : c8, lo = R > c8 ? c8 : R;
-            wv[s][r] = *(left ? D0 + hi * CB + lo : E0 + c8 * CB + R);
-            wv[s][r + 2] = *(left ? E0 + R * CB + c8 : D1 + hi * CB + lo);
-        }
-        const bool side = p >= 1;
-        const double *Em = E + (size_t)(side ? p - 1 : 0) * CBB;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const double v = Em[(4 * r + g) * CB + c8];
-            sdv[s][r] = (side && left) ? v : 0.0;
+            wv[s][r] = *(left ? W0 + hi * CB + lo : WE + c8 * CB + R);
+            wv[s][r + 2] = *(left ? WE + R * CB + c8 : W1 + hi * CB + lo);
+            const double v = WM[(4 * r + g) * CB + c8];
+            sdv[s][r] = (p >= 1 && left) ? v : 0.0;
         }
     }
     // the elimination of this wavefront, if this wave holds it (at most one, the last item): its Q and E_j
@@ -523,12 +541,13 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
     if (diag && (((blockIdx.x & 7) | (blockIdx.y & 7)) != 0)) diag = nullptr;   // one wave in 64 reports (the sums are atomics)
     __shared__ __attribute__((aligned(16))) double Qs[NW][4][16 * QLD];  // per wave and item slot: Q, row-major, stride QLD
     __shared__ __attribute__((aligned(16))) double Bc[NW][4][16];        // per wave and item slot: the row that goes round
+    __shared__ __attribute__((aligned(16))) double Ws[NW][4][4 * CBB];   // per wave and item slot: D_p, D_{p+1}, E_p, E_{p-1} (phase B's operands)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // ipw = items per wave: 4; 2 or 1 only as an experiment (BSP_CW_IPW).  An item's arithmetic does not depend on the slot it
     // sits in: the choice changes no bit (tests/test_gpu_solve.py::test_band_route_properties).
     cw_quad<ONEDIV>(N, t, jlo, nch, jel, ipw, nlh, qstride, nlead, (int)blockIdx.y, (blockIdx.x * NW + wave) * ipw, lane, &Qs[wave][0][0],
-                    &Bc[wave][0][0], Qel, Dall, Eall, Gall, diag);
+                    &Bc[wave][0][0], &Ws[wave][0][0], Qel, Dall, Eall, Gall, diag);
 }
 
 // index-reversed overlap band: SBf[d][i] = S_f(i, i + d) = S(n-1-i-d, n-1-i)
