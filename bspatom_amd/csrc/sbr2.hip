@@ -866,6 +866,10 @@ __global__ __launch_bounds__(576) void sb16st_kernel(int n, int npad, int batch,
 // was) and 8 (half-width <= 8: what the band route's reduction really leaves, crawford.hip).  With B = 8 an item is owned by HALF a
 // DPP row, a wave runs EIGHT sweeps and a pass sixteen; a window column has 16 rows; everything else is the same program.
 constexpr int NCW4 = 6, SB16R_THREADS = (NCW4 + 1) * 64;
+// window element at BYTE offset `off` (the tile addresses of the chasing waves are kept in bytes: as indices every access
+// paid a shift, 16 vector instructions per step of a role)
+__device__ __forceinline__ double &ldsb(double *Lw, int off) { return *reinterpret_cast<double *>(reinterpret_cast<char *>(Lw) + off); }
+
 template <int B>
 struct Rw {
     static constexpr int WR = 2 * B;                   // rows of a window column: the band and what the sweeps leave of their bulges
@@ -918,24 +922,24 @@ __device__ __forceinline__ void next_reflector(double *Lw, const double x0, cons
     const double beta = nz ? beta0 : alpha, tq = nz ? tq0 : 0.0, scale = nz ? scale0 : 0.0;
     Lw[xw + j] = j == 0 ? 1.0 : x0 * scale;
     if (j == 0) Lw[xw + B] = tq;
-    Lw[hx] = j == 0 ? beta : 0.0;
+    ldsb(Lw, hx) = j == 0 ? beta : 0.0;                                 // hx: a byte offset
 }
 
-// Window index of the element (r0 + B + j, r0 + i) of an item's next tile, i = 0 .. B - 1, as base[i] + (WR - 1) i: the column
+// Window BYTE offset of the element (r0 + B + j, r0 + i) of an item's next tile, i = 0 .. B - 1, as base[i] + 8 (WR - 1) i: the column
 // r0 + i wraps around the ring from i = 512 - (r0 mod 512) on
 template <int B, bool FAST>                                            // FAST: no tile of the wave wraps
 __device__ __forceinline__ void next_tile_addr(const int r0, const int j, int (&at)[B])
 {
-    const int cb = r0 & (WCOLS - 1), a0 = (cb << Rw<B>::WSH) + B + j, iw = WCOLS - cb;
+    const int cb = r0 & (WCOLS - 1), a0 = ((cb << Rw<B>::WSH) + B + j) * 8, iw = WCOLS - cb;
 #pragma unroll
-    for (int i = 0; i < B; ++i) at[i] = (FAST || i < iw) ? a0 : a0 - WCOLS * Rw<B>::WR;
+    for (int i = 0; i < B; ++i) at[i] = (FAST || i < iw) ? a0 : a0 - WCOLS * Rw<B>::WR * 8;
 }
-// ... of the element D(i, j) of its diagonal tile, from the stored triangle: column r0 + min(i, j) (wraps when both do),
-// (WR - 1) min + max
+// ... of the element D(i, j) of its diagonal tile (bytes; offD in bytes), from the stored triangle: column r0 + min(i, j) (wraps
+// when both do), (WR - 1) min + max
 template <int B, bool FAST>
 __device__ __forceinline__ void diag_tile_addr(const int r0, const int j, const int (&offD)[B], int (&ad)[B])
 {
-    const int cb = r0 & (WCOLS - 1), ud = cb << Rw<B>::WSH, iw = WCOLS - cb, udq = j >= iw ? ud - WCOLS * Rw<B>::WR : ud;
+    const int cb = r0 & (WCOLS - 1), ud = (cb << Rw<B>::WSH) * 8, iw = WCOLS - cb, udq = j >= iw ? ud - WCOLS * Rw<B>::WR * 8 : ud;
 #pragma unroll
     for (int i = 0; i < B; ++i) ad[i] = ((!FAST && i >= iw) ? udq : ud) + offD[i];
 }
@@ -954,7 +958,7 @@ __device__ __forceinline__ void chase4_next(double *Lw, double (&bt)[B], const d
     const double ct = tq * ((y0 + y1) + (y2 + y3));
     next_reflector<B>(Lw, bt[0] - ct, j, xw, at[0]);                 // B'(j, 0): element j of the next item's column
 #pragma unroll
-    for (int i = 1; i < B; ++i) Lw[at[i] + (Rw<B>::WR - 1) * i] = fma(-ct, v[i], bt[i]);
+    for (int i = 1; i < B; ++i) ldsb(Lw, at[i] + (Rw<B>::WR - 1) * 8 * i) = fma(-ct, v[i], bt[i]);
 }
 
 // role 1: diagonal tile d (lane j = column j) <- H d H; (v, tau) from slot xr
@@ -981,7 +985,7 @@ __device__ __forceinline__ void chase4_diag(double *Lw, const double (&d)[B], co
     for (int i = 0; i < B; ++i) zz[i] = Lw[zi + i];
     // the lower triangle is what the band stores; the mirrored values go to the dump (a select on the address, no branch)
 #pragma unroll
-    for (int i = 0; i < B; ++i) Lw[i >= j ? ad[i] : dumpi + i] = fma(-zz[i], vl, fma(-v[i], z, d[i]));
+    for (int i = 0; i < B; ++i) ldsb(Lw, i >= j ? ad[i] : (dumpi + i) * 8) = fma(-zz[i], vl, fma(-v[i], z, d[i]));
 }
 
 // role 2: bulge tile of item (r0, c0): column c0 + j, rows r0 .. r0 + B - 1 (contiguous; no wrap inside a lane).  Column 0 holds
@@ -1180,7 +1184,7 @@ __global__ __launch_bounds__(SB16R_THREADS) void sbr_rows_kernel(int n, int npad
         // the reflector of the pass's first item (sweep s0, k = 0) into its slot of step 0
         if (wv == 0 && g == 0) {
             const int hx = ((s0 & (WCOLS - 1)) << WSH) + 1 + j;
-            next_reflector<B>(Lw, Lw[hx], j, W::XS, hx);
+            next_reflector<B>(Lw, Lw[hx], j, W::XS, hx * 8);
         }
         const int nsteps = (n - s0 - 1 + B - 1) / B + LAG * (NSW - 1);
 #define SB16R_RPN(t) \
@@ -1226,7 +1230,7 @@ __global__ __launch_bounds__(SB16R_THREADS) void sbr_rows_kernel(int n, int npad
                 if (sw == 0 && live && s4 + 1 < n) {      // item (s0, 0) runs at step 0
                     next_tile_addr<B, false>(s4 + 1, j, at);
 #pragma unroll
-                    for (int i = 0; i < B; ++i) { bt[i] = Lw[at[i] + (WR - 1) * i]; v[i] = Lw[xs0 + i]; }
+                    for (int i = 0; i < B; ++i) { bt[i] = ldsb(Lw, at[i] + (WR - 1) * 8 * i); v[i] = Lw[xs0 + i]; }
                     tq = Lw[xs0 + B];
                 }
                 __syncthreads();
@@ -1239,7 +1243,7 @@ __global__ __launch_bounds__(SB16R_THREADS) void sbr_rows_kernel(int n, int npad
                         chase4_next<B>(Lw, bt, v, tq, at, j, xw);
                     } else if (k4 == -1 && live) {        // the sweep starts in the next step: its reflector from the band column
                         const int hx = ((s4 & (WCOLS - 1)) << WSH) + 1 + j;
-                        next_reflector<B>(Lw, Lw[hx], j, xw, hx);
+                        next_reflector<B>(Lw, Lw[hx], j, xw, hx * 8);
                     }
                     // for the next step: (v, tau) back from the slot, the next item's tile (general addresses for the whole wave
                     // if the tile of one of its items wraps around the ring)
@@ -1251,7 +1255,7 @@ __global__ __launch_bounds__(SB16R_THREADS) void sbr_rows_kernel(int n, int npad
                         for (int i = 0; i < B; ++i) v[i] = Lw[xw + i];
                         tq = Lw[xw + B];
 #pragma unroll
-                        for (int i = 0; i < B; ++i) bt[i] = Lw[at[i] + (WR - 1) * i];
+                        for (int i = 0; i < B; ++i) bt[i] = ldsb(Lw, at[i] + (WR - 1) * 8 * i);
                     }
                     if (DIAG) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[2] += t_ - dt0; dt0 = t_; }
                     if (__builtin_amdgcn_ballot_w64(actN) != 0) stores_done_barrier<B>();
@@ -1261,11 +1265,11 @@ __global__ __launch_bounds__(SB16R_THREADS) void sbr_rows_kernel(int n, int npad
             } else if (role == 1) {
                 double d[B];
                 int ad[B], offD[B];
-                for (int i = 0; i < B; ++i) { d[i] = 0.0; ad[i] = 0; offD[i] = i >= j ? (WR - 1) * j + i : (WR - 1) * i + j; }
+                for (int i = 0; i < B; ++i) { d[i] = 0.0; ad[i] = 0; offD[i] = (i >= j ? (WR - 1) * j + i : (WR - 1) * i + j) * 8; }
                 if (sw == 0 && live && s4 + 1 < n) {
                     diag_tile_addr<B, false>(s4 + 1, j, offD, ad);
 #pragma unroll
-                    for (int i = 0; i < B; ++i) d[i] = Lw[ad[i]];
+                    for (int i = 0; i < B; ++i) d[i] = ldsb(Lw, ad[i]);
                 }
                 __syncthreads();
                 for (int t = 0; t < nsteps; ++t) {
@@ -1278,7 +1282,7 @@ __global__ __launch_bounds__(SB16R_THREADS) void sbr_rows_kernel(int n, int npad
                         if (wrapN) diag_tile_addr<B, false>(r04 + B, j, offD, ad);
                         else diag_tile_addr<B, true>(r04 + B, j, offD, ad);
 #pragma unroll
-                        for (int i = 0; i < B; ++i) d[i] = Lw[ad[i]];
+                        for (int i = 0; i < B; ++i) d[i] = ldsb(Lw, ad[i]);
                     }
                     if (DIAG) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); dacc[2] += t_ - dt0; dt0 = t_; }
                     if (__builtin_amdgcn_ballot_w64(actN) != 0) stores_done_barrier<B>();
