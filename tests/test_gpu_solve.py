@@ -695,9 +695,10 @@ def test_band_route_properties():
     note("band route vs dense route, 12 channels n=1024: normwise %.2e, worst relative %.2e" % (
         np.max(np.abs(E0 - Ed)) / lam, np.max(np.abs(E0 - Ed) / np.abs(Ed))))
     assert np.max(np.abs(E0 - Ed)) <= 1e-13 * lam
-    # ... and however many chase items a wave of the band reduction takes, waves a workgroup has or streams its channels are spread over
+    # ... and however many chase items a wave of the band reduction takes, waves a workgroup has or streams its channels are spread over,
+    # and with the S-only part of the reduction on the main stream instead of beside the assembly
     for kw in [dict(), dict(sb2st_ring=8), dict(sb2st_ring=4), dict(sb2st_ring=2), dict(sb2st_ring=1), dict(sb2st_force_abort=1),
-               dict(sb2st_force_abort=2), dict(cw_ipw=1), dict(cw_ipw=2), dict(cw_ipw=4), dict(cw_nw=4), dict(cw_streams=1), dict(cw_streams=3)]:
+               dict(sb2st_force_abort=2), dict(cw_ipw=1), dict(cw_ipw=2), dict(cw_ipw=4), dict(cw_nw=4), dict(cw_streams=1), dict(cw_streams=3), dict(s_overlap=0)]:
         with _Options(**kw):
             E, info = prob.solve(0, 12)
         assert np.all(info == 0), kw
