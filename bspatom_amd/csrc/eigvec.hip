@@ -15,7 +15,6 @@
 namespace bsp {
 
 constexpr int EB_MAX = 15;                 // half-bandwidth limit (k <= 16)
-constexpr int EWC = 2 * EB_MAX + 2;        // window column slots
 
 __device__ __forceinline__ double pencil_entry(const double *__restrict__ SB, const double *__restrict__ HB,
                                                int n, int b, double E, int r, int c)
@@ -62,6 +61,8 @@ __device__ __forceinline__ double ev_row0_max(double x)          // max over lan
 // round trip into every column of the factorisation.
 __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// BT >= b = k - 1: rows of the register window (instances 8 and 15)
+template <int BT>
 __global__ __launch_bounds__(64) void invit_kernel(int n, int k, const double *__restrict__ SB,
                                                   const double *__restrict__ HBall,
                                                   const int *__restrict__ chan, const double *__restrict__ Eall,
@@ -69,12 +70,10 @@ __global__ __launch_bounds__(64) void invit_kernel(int n, int k, const double *_
 {
     extern __shared__ double y[];                       // n doubles
     // one wavefront on a chain of dependent steps, usually beside the batched bisection whose waves are pure VALU work:
-    // issue priority over them (19 ms beside that kernel without, 11 ms alone)
+    // issue priority over them
     __builtin_amdgcn_s_setprio(3);
-    __shared__ double Wd[EB_MAX + 1][EWC];
-    __shared__ double xs[64];
     const int lane = threadIdx.x;
-    const int b = k - 1, WC = 2 * b + 2, NR = b + 1;
+    const int b = k - 1;
     const size_t iv = blockIdx.x;
     const double E = Eall[iv];
     const double *HB = HBall + (size_t)chan[iv] * k * n;
@@ -89,147 +88,155 @@ __global__ __launch_bounds__(64) void invit_kernel(int n, int k, const double *_
     for (int off = 32; off >= 1; off >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, off));
     const double pertol = 2.220446049250313e-16 * fmax(dmax, 1e-300);
 
-    // ---- banded LU with partial pivoting ----
-    for (int idx = lane; idx < NR * WC; idx += 64) {
-        const int r = idx / WC, cs = idx % WC;          // rows 0..b, columns 0..2b+1 at start
-        Wd[r % NR][cs] = pencil_entry(SB, HB, n, b, E, r, cs);
-    }
-    lds_sync();
-    // The row that enters the window at step j (row j+b+1) does not depend on the elimination: its entries are
-    // fetched PF steps at a time (one per lane and step), so that the memory latency is paid once per PF columns
-    // and not in every one of the n dependent steps (the kernel is one wavefront: 4.5 us per column before).
-    constexpr int PF = 8;
-    double pe[PF];
-    // Ring positions are kept incrementally (j mod NR, j mod WC and their sums with small offsets wrap at most once):
-    // NR = k and WC = 2k are not powers of two, and an integer division is ~20 instructions -- a dozen of them per
-    // column were most of this loop.  The element (t, cc) pairs a lane eliminates are fixed: computed once.
-    constexpr int EQ = (EB_MAX * 2 * EB_MAX + 63) / 64;     // lane's elements of the rank-1 update: idx = lane + 64 q
-    int et[EQ], ec[EQ];
+    // ---- banded LU with partial pivoting (LINPACK dgbfa's row window), the window in REGISTERS (round 4): lane c (0 .. 2 b) holds
+    // column j + c of the rows j .. j + b, a[t] = M(j + t, j + c).  The pivot search runs down lane 0's registers, the pivot row
+    // and the multipliers go round by readlane, the rank-1 update is b multiply-adds inside every lane, and the window slides
+    // by renaming its rows and a one-lane DPP shift of its columns: no LDS, no barrier in the n dependent steps.  (The first
+    // form kept the window as a ring in LDS with five barriers and as many dependent LDS round trips per column: ~2.5 us per
+    // column, 10 of the kernel's 11 ms.)  Pivot choice, perturbation of a vanishing pivot, multipliers and updates are the first
+    // form's, operation for operation. ----
+    double a[BT + 1];
 #pragma unroll
-    for (int q = 0; q < EQ; ++q) {
-        const int idx = lane + 64 * q;
-        et[q] = (idx < b * 2 * b) ? 1 + idx / (2 * b) : 0;   // 0: no element
-        ec[q] = 1 + idx % (2 * b);
-    }
-    auto wrapN = [&](int r) { return (r >= NR) ? r - NR : r; };
-    auto wrapW = [&](int c) { return (c >= WC) ? c - WC : c; };
-    int jN = 0, jW = 0;                                      // j mod NR, j mod WC
+    for (int t = 0; t <= BT; ++t) a[t] = (t <= b && lane <= 2 * b) ? pencil_entry(SB, HB, n, b, E, t, lane) : 0.0;
+    // The row that enters the window at step j (row j + b + 1) does not depend on the elimination: its entries are fetched PF
+    // steps at a time (one per lane and step), so that the memory latency is paid once per PF columns
+    // ... and a block AHEAD: requested at the start of a block for the next one (with one buffer every block of PF dependent steps
+    // began with a full round trip to memory -- 512 of them per pass over the matrix, most of what this kernel took)
+    constexpr int PF = 8;
+    double pe[PF], pn[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) pn[u] = (lane <= 2 * b) ? pencil_entry(SB, HB, n, b, E, u + b + 1, u + 1 + lane) : 0.0;
     for (int j = 0; j < n; ++j) {
         if ((j & (PF - 1)) == 0) {
-            int c0 = wrapW(jW + 1);                          // (ju + 1) mod WC for ju = j
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                const int ju = j + u, rn = ju + b + 1;
-                int dcs = lane - c0; dcs = (dcs < 0) ? dcs + WC : dcs;          // (lane - (ju+1) mod WC) mod WC for lane < WC
-                const int c = (ju + 1) + dcs;
-                pe[u] = (lane < WC && rn < n) ? pencil_entry(SB, HB, n, b, E, rn, c) : 0.0;
-                c0 = wrapW(c0 + 1);
+                pe[u] = pn[u];
+                pn[u] = (lane <= 2 * b) ? pencil_entry(SB, HB, n, b, E, j + PF + u + b + 1, j + PF + u + 1 + lane) : 0.0;
             }
         }
         const int nrow = (n - 1 - j < b) ? (n - 1 - j) : b;       // rows below the pivot row
-        const int rl = wrapN(jN + ((lane <= b) ? lane : 0));       // ring row of matrix row j + lane (lane <= b)
-        // pivot search over rows j .. j+nrow in column j
-        // (rows j .. j+nrow sit in lanes 0 .. nrow <= 15: the first DPP row; ties go to the smallest row)
-        const double av = (lane <= nrow) ? fabs(Wd[rl][jW]) : 0.0;
-        const double mxv = ev_row0_max(av);
-        const unsigned long long hit = __ballot(lane <= nrow && av == mxv);
-        const int dp = hit ? (__ffsll((long long)hit) - 1) : 0;
-        const int p = j + dp;
-        if (dp != 0) {
-            const int pN = wrapN(jN + dp);
-            if (lane < WC) {
-                const double t1 = Wd[jN][lane];
-                Wd[jN][lane] = Wd[pN][lane];
-                Wd[pN][lane] = t1;
-            }
+        // pivot search over rows j .. j + nrow in column j (lane 0's registers); ties go to the smallest row
+        double mxv = fabs(a[0]);
+        int dpl = 0;
+#pragma unroll
+        for (int t = 1; t <= BT; ++t) {
+            const double v = (t <= nrow) ? fabs(a[t]) : -1.0;
+            if (v > mxv) { mxv = v; dpl = t; }
         }
-        lds_sync();
-        double pv = Wd[jN][jW];
+        const int dp = __builtin_amdgcn_readfirstlane(dpl);
+        if (dp != 0) {                                               // uniform: rows j and j + dp change places, in every column
+#pragma unroll
+            for (int t = 1; t <= BT; ++t)
+                if (t == dp) { const double t1 = a[0]; a[0] = a[t]; a[t] = t1; }
+        }
+        double pv = ev_readlane(a[0], 0);
         if (fabs(pv) < pertol) pv = (pv < 0.0) ? -pertol : pertol;
-        double lt = 0.0;
         const double rpv = 1.0 / pv;
-        if (lane >= 1 && lane <= nrow) lt = Wd[rl][jW] * rpv;
-        lds_sync();
-        if (lane == 0) { Wd[jN][jW] = pv; piv[j] = (double)p; }
-        if (lane >= 1 && lane <= nrow) Wd[rl][jW] = 0.0;
-        if (lane >= 1 && lane <= b) Lm[(size_t)j * b + lane - 1] = lt;
-        xs[lane] = lt;
-        lds_sync();
-        // elimination: rows t = 1..nrow, columns cc = 1..2b
+        double lmine = 0.0;                                          // this lane's multiplier (row j + lane), for the store
 #pragma unroll
-        for (int q = 0; q < EQ; ++q) {
-            if (q * 64 < b * 2 * b) {                               // uniform: this k needs round q at all
-                const int t = et[q];
-                if (t >= 1 && t <= nrow) {
-                    const int cs = wrapW(jW + ec[q]);
-                    Wd[wrapN(jN + t)][cs] -= xs[t] * Wd[jN][cs];
-                }
-            }
+        for (int t = 1; t <= BT; ++t) {
+            const double lt = (t <= nrow) ? ev_readlane(a[t], 0) * rpv : 0.0;
+            lmine = (lane == t) ? lt : lmine;
+            a[t] = (lane >= 1) ? a[t] - lt * a[0] : 0.0;             // columns j + 1 .. j + 2 b; column j is eliminated
         }
-        // store U row j
-        if (lane <= 2 * b) U[(size_t)j * (2 * b + 1) + lane] = Wd[jN][wrapW(jW + lane)];
-        lds_sync();
-        // slide the window: row j leaves, row j+b+1 enters (columns j+1 .. j+2b+1; slot of j cleared)
-        // (slot cs = lane holds the absolute column (j+1) + ((cs - (j+1) % WC) mod WC) of [j+1, j+2b+2))
-        {
-            double pv_ = pe[0];
+        if (lane == 0) { a[0] = pv; piv[j] = (double)(j + dp); }
+        if (lane <= 2 * b) U[(size_t)j * (2 * b + 1) + lane] = a[0];
+        if (lane >= 1 && lane <= b) Lm[(size_t)j * b + lane - 1] = lmine;
+        // slide the window: row j leaves, row j + b + 1 enters; column j leaves, column j + 2 b + 1 enters (zero above the entering row)
+        double pin = pe[0];
 #pragma unroll
-            for (int u = 1; u < PF; ++u) pv_ = ((j & (PF - 1)) == u) ? pe[u] : pv_;
-            if (lane < WC) Wd[jN][lane] = pv_;
-        }
-        lds_sync();
-        jN = wrapN(jN + 1); jW = wrapW(jW + 1);
+        for (int u = 1; u < PF; ++u) pin = ((j & (PF - 1)) == u) ? pe[u] : pin;
+#pragma unroll
+        for (int t = 0; t < BT; ++t) a[t] = ev_dpp<0x130>(a[t + 1]);  // wave_shl:1 -- lane c takes lane c + 1
+        a[BT] = 0.0;
+#pragma unroll
+        for (int t = 0; t <= BT; ++t)
+            if (t == b) a[t] = pin;                                  // uniform
     }
 
     // ---- inverse iteration: 3 solves ----
     for (int j = lane; j < n; j += 64) y[j] = 1.0;
     __syncthreads();                                   // also: U, L, piv are in memory (vmcnt(0))
     for (int iter = 0; iter < 3; ++iter) {
-        // forward: y <- L^-1 P y
-        for (int j0 = 0; j0 < n; j0 += PF) {
-            double lv[PF], pvv[PF];                      // multipliers and pivot rows of PF steps: independent of y
+        // forward: y <- L^-1 P y.  The b + 1 entries y[j .. j + b] that step j can touch live in a REGISTER window, lane i holding
+        // y[j + i]: the pivot value goes round by readlane, the window moves on by a one-lane DPP shift, the entry that enters
+        // it comes from LDS a block of PF steps ahead and the finished y[j] goes back there without anybody waiting for it --
+        // no LDS round trip, no barrier inside the n dependent steps.  The operations and their order are the first form's.
+        {
+            double w = (lane <= b && lane < n) ? y[lane] : 0.0;
+            double lvn[PF], pvn[PF];                     // the next block's multipliers and pivot rows, requested a block ahead
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                const int j = j0 + u;
-                lv[u] = (j < n && lane >= 1 && lane <= b) ? Lm[(size_t)j * b + lane - 1] : 0.0;
-                pvv[u] = (j < n) ? piv[j] : 0.0;
+                lvn[u] = (u < n && lane >= 1 && lane <= b) ? Lm[(size_t)u * b + lane - 1] : 0.0;
+                pvn[u] = (u < n) ? piv[u] : 0.0;
             }
+            for (int j0 = 0; j0 < n; j0 += PF) {
+                double lv[PF], pvv[PF], yin[PF];         // multipliers, pivot rows, entering entries of PF steps: independent of the recurrence
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int j = j0 + u;
-                if (j < n) {
-                    const int p = (int)pvv[u];
-                    if (p != j) {
-                        if (lane == 0) { const double t1 = y[j]; y[j] = y[p]; y[p] = t1; }
-                        lds_sync();
+                for (int u = 0; u < PF; ++u) {
+                    const int j = j0 + u, jn = j + PF;
+                    lv[u] = lvn[u]; pvv[u] = pvn[u];
+                    lvn[u] = (jn < n && lane >= 1 && lane <= b) ? Lm[(size_t)jn * b + lane - 1] : 0.0;
+                    pvn[u] = (jn < n) ? piv[jn] : 0.0;
+                    yin[u] = (j + b + 1 < n) ? y[j + b + 1] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int j = j0 + u;
+                    if (j < n) {
+                        const int p = (int)pvv[u];
+                        if (p != j) {                                    // uniform: rows j and p change places (p - j <= b: inside the window)
+                            const double t0 = ev_readlane(w, 0), tq = ev_readlane(w, p - j);
+                            w = lane == 0 ? tq : (lane == p - j ? t0 : w);
+                        }
+                        const double yj = ev_readlane(w, 0);
+                        const int nrow = (n - 1 - j < b) ? (n - 1 - j) : b;
+                        if (lane >= 1 && lane <= nrow) w -= lv[u] * yj;
+                        if (lane == 0) y[j] = yj;
+                        w = ev_dpp<0x130>(w);                            // wave_shl:1 -- lane i takes lane i + 1
+                        if (lane == b) w = yin[u];
                     }
-                    const double yj = y[j];
-                    const int nrow = (n - 1 - j < b) ? (n - 1 - j) : b;
-                    if (lane >= 1 && lane <= nrow) y[j + lane] -= lv[u] * yj;
-                    lds_sync();
                 }
             }
+            lds_sync();
         }
-        // backward: x_j = (y_j - sum_{cc=1..2b} U[j][cc] x_{j+cc}) / U[j][0]
-        for (int j0 = n - 1; j0 >= 0; j0 -= PF) {
-            double uv[PF], ru[PF];                       // row j of U: lane cc holds U[j][cc]; 1 / U[j][0] for every lane
+        // backward: x_j = (y_j - sum_{cc=1..2b} U[j][cc] x_{j+cc}) / U[j][0], the 2 b entries x[j + 1 .. j + 2 b] in a register window
+        // likewise (lane cc holds x[j + cc]; zero beyond the matrix)
+        {
+            double w = 0.0;
+            double uvn[PF], udn[PF];                     // the next block's rows of U and their pivots, requested a block ahead
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                const int j = j0 - u;
-                uv[u] = (j >= 0 && lane >= 1 && lane <= 2 * b) ? U[(size_t)j * (2 * b + 1) + lane] : 0.0;
-                ru[u] = (j >= 0) ? 1.0 / U[(size_t)j * (2 * b + 1)] : 0.0;
+                const int j = n - 1 - u;
+                uvn[u] = (j >= 0 && lane >= 1 && lane <= 2 * b) ? U[(size_t)j * (2 * b + 1) + lane] : 0.0;
+                udn[u] = (j >= 0) ? U[(size_t)j * (2 * b + 1)] : 1.0;
             }
+            for (int j0 = n - 1; j0 >= 0; j0 -= PF) {
+                double uv[PF], ru[PF], yv[PF];           // row j of U: lane cc holds U[j][cc]; 1 / U[j][0] and y[j] for every lane
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int j = j0 - u;
-                if (j >= 0) {
-                    double s = 0.0;
-                    if (lane >= 1 && lane <= 2 * b && j + lane < n) s = uv[u] * y[j + lane];
-                    s = ev_wave_sum(s);
-                    if (lane == 0) y[j] = (y[j] - s) * ru[u];
-                    lds_sync();
+                for (int u = 0; u < PF; ++u) {
+                    const int j = j0 - u, jn = j - PF;
+                    uv[u] = uvn[u];
+                    ru[u] = (j >= 0) ? 1.0 / udn[u] : 0.0;
+                    uvn[u] = (jn >= 0 && lane >= 1 && lane <= 2 * b) ? U[(size_t)jn * (2 * b + 1) + lane] : 0.0;
+                    udn[u] = (jn >= 0) ? U[(size_t)jn * (2 * b + 1)] : 1.0;
+                    yv[u] = (j >= 0) ? y[j] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int j = j0 - u;
+                    if (j >= 0) {
+                        double s2 = 0.0;
+                        if (lane >= 1 && lane <= 2 * b && j + lane < n) s2 = uv[u] * w;
+                        s2 = ev_wave_sum(s2);
+                        const double xj = (yv[u] - s2) * ru[u];
+                        if (lane == 0) y[j] = xj;
+                        w = ev_dpp<0x138>(w);                            // wave_shr:1 -- lane i takes lane i - 1
+                        if (lane == 1) w = xj;
+                    }
                 }
             }
+            lds_sync();
         }
         // normalise by max-abs, then rhs = S x for the next iteration
         double mx = 0.0;
@@ -302,11 +309,14 @@ int launch_inverse_iteration(int n, int k, int nvec, const double *d_SB, const d
     if (lds > 140 * 1024) return BSP_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(invit_kernel),
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(invit_kernel<8>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(invit_kernel<EB_MAX>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(invit_kernel, dim3(nvec), dim3(64), lds, st, n, k, d_SB, d_HB, d_chan, d_E, d_work, d_vec, d_info);
+    if (k - 1 <= 8) hipLaunchKernelGGL(invit_kernel<8>, dim3(nvec), dim3(64), lds, st, n, k, d_SB, d_HB, d_chan, d_E, d_work, d_vec, d_info);
+    else hipLaunchKernelGGL(invit_kernel<EB_MAX>, dim3(nvec), dim3(64), lds, st, n, k, d_SB, d_HB, d_chan, d_E, d_work, d_vec, d_info);
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }
