@@ -23,8 +23,10 @@ namespace bsp {
 // run from both ends (crawford.hip) wants the leading half of the factor of S and of the index-reversed S, side by side.
 // BMAX = the largest half-width of the instance (8: every pencil of the band route; the sum over the previous rows has BMAX terms in
 // a dependent chain, masked down to b, so the narrow instance halves the longest chain of a column; same terms, same order)
+// Rows jstart .. jstop - 1: a launch may continue where another stopped (the rows j - b .. j - 1 it needs come back from UB: the same
+// doubles), so that the band route can start on the first blocks while the rest of the factor is still being computed.
 template <int BMAX>
-__global__ __launch_bounds__(64) void band_cholesky_kernel(int n, int k, int jstop, const double *__restrict__ SB0,
+__global__ __launch_bounds__(64) void band_cholesky_kernel(int n, int k, int jstart, int jstop, const double *__restrict__ SB0,
                                                           double *__restrict__ UB0,
                                                           double *__restrict__ rdiag0, int *info)
 {
@@ -36,12 +38,16 @@ __global__ __launch_bounds__(64) void band_cholesky_kernel(int n, int k, int jst
     int bad = 0;
     const bool row = t <= b;
     const double *Sb = SB + (size_t)(row ? t : 0) * n;
-    for (int e = t; e < RING * (BMAX + 1); e += 64) (&ring[0][0])[e] = 0.0;     // rows before the matrix: zeros (no bounds tests below)
+    for (int e = t; e < RING * (BMAX + 1); e += 64) {                          // rows before the matrix: zeros (no bounds tests below);
+        const int slot = e / (BMAX + 1), d = e % (BMAX + 1);                   // rows before jstart: what the launch before left in UB
+        const int pr = jstart - RING + ((slot - jstart) & (RING - 1));         // the row of [jstart - RING, jstart) that lives in this slot
+        (&ring[0][0])[e] = (pr >= 0 && d <= b && pr + d < n) ? UB[(size_t)d * n + pr] : 0.0;
+    }
     double cur[CH], nxt[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) cur[c] = (row && c < n) ? Sb[c] : 0.0;
+    for (int c = 0; c < CH; ++c) cur[c] = (row && jstart + c < n) ? Sb[jstart + c] : 0.0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    for (int j0 = 0; j0 < jstop; j0 += CH) {
+    for (int j0 = jstart; j0 < jstop; j0 += CH) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) { const int j = j0 + CH + c; nxt[c] = (row && j < n) ? Sb[j] : 0.0; }   // in flight during this chunk
 #pragma unroll
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(64) void band_cholesky_kernel(int n, int k, int jst
             r.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
             r.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
             const double piv = r.d;
-            if (!(piv > 0.0) && bad == 0) { bad = 1; if (t == 0) *info = j + 1; }   // minor j+1 not PD
+            if (!(piv > 0.0) && bad == 0) { bad = 1; if (t == 0 && *info == 0) *info = j + 1; }   // minor j+1 not PD (the first one, over all launches)
             const double dj = sqrt(piv);
             double uv = (t == 0) ? dj : s / dj;
             if (t <= BMAX) {
@@ -189,8 +195,19 @@ int launch_band_cholesky(int n, int k, const double *d_SB, double *d_UB, double 
                          hipStream_t st)
 {
     if (k - 1 > 16 || k < 2) return BSP_ERR_ARG;
-    if (k - 1 <= 8) hipLaunchKernelGGL(band_cholesky_kernel<8>, dim3(1), dim3(64), 0, st, n, k, n, d_SB, d_UB, d_rdiag, d_info);
-    else hipLaunchKernelGGL(band_cholesky_kernel<16>, dim3(1), dim3(64), 0, st, n, k, n, d_SB, d_UB, d_rdiag, d_info);
+    if (k - 1 <= 8) hipLaunchKernelGGL(band_cholesky_kernel<8>, dim3(1), dim3(64), 0, st, n, k, 0, n, d_SB, d_UB, d_rdiag, d_info);
+    else hipLaunchKernelGGL(band_cholesky_kernel<16>, dim3(1), dim3(64), 0, st, n, k, 0, n, d_SB, d_UB, d_rdiag, d_info);
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
+
+// rows jstart .. jstop - 1, continuing a factorisation whose rows before jstart are in d_UB (jstart a multiple of 16)
+int launch_band_cholesky_range(int n, int k, int jstart, int jstop, const double *d_SB, double *d_UB, double *d_rdiag, int *d_info,
+                               hipStream_t st)
+{
+    if (k - 1 > 16 || k < 2 || jstart < 0 || jstart % 16 != 0 || jstop <= jstart || jstop > n) return BSP_ERR_ARG;
+    if (k - 1 <= 8) hipLaunchKernelGGL(band_cholesky_kernel<8>, dim3(1), dim3(64), 0, st, n, k, jstart, jstop, d_SB, d_UB, d_rdiag, d_info);
+    else hipLaunchKernelGGL(band_cholesky_kernel<16>, dim3(1), dim3(64), 0, st, n, k, jstart, jstop, d_SB, d_UB, d_rdiag, d_info);
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }
@@ -199,8 +216,8 @@ int launch_band_cholesky(int n, int k, const double *d_SB, double *d_UB, double 
 int launch_band_cholesky_pair(int n, int k, int jstop, const double *d_SB, double *d_UB, double *d_rdiag, int *d_info, hipStream_t st)
 {
     if (k - 1 > 16 || k < 2 || jstop < 1 || jstop > n) return BSP_ERR_ARG;
-    if (k - 1 <= 8) hipLaunchKernelGGL(band_cholesky_kernel<8>, dim3(2), dim3(64), 0, st, n, k, jstop, d_SB, d_UB, d_rdiag, d_info);
-    else hipLaunchKernelGGL(band_cholesky_kernel<16>, dim3(2), dim3(64), 0, st, n, k, jstop, d_SB, d_UB, d_rdiag, d_info);
+    if (k - 1 <= 8) hipLaunchKernelGGL(band_cholesky_kernel<8>, dim3(2), dim3(64), 0, st, n, k, 0, jstop, d_SB, d_UB, d_rdiag, d_info);
+    else hipLaunchKernelGGL(band_cholesky_kernel<16>, dim3(2), dim3(64), 0, st, n, k, 0, jstop, d_SB, d_UB, d_rdiag, d_info);
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }

@@ -37,7 +37,7 @@ struct bspatom_problem {
     hipStream_t st2 = nullptr;
     hipEvent_t evx = nullptr;
     hipStream_t stS = nullptr;                // band route: the S-only part of the reduction beside the assembly of the H_l
-    hipEvent_t evS = nullptr, evP = nullptr;
+    hipEvent_t evS = nullptr, evC[bsp::CW_CHUNKS] = {};
     double *d_pvec = nullptr, *d_pE = nullptr;
     int *d_pinfo = nullptr;
     int pre_l = -1, pre_n0 = -1, pre_ch = 0;
@@ -80,7 +80,7 @@ const OptName OPT_TABLE[] = {
     {"poison_c", "BSP_POISON_C", &Options::poison_c}, {"sb2sb_mfma", "BSP_SB2SB_MFMA", &Options::sb2sb_mfma},
     {"ktime", "BSP_KTIME", &Options::ktime}, {"tsqr_regcap", "BSP_TSQR_REGCAP", &Options::tsqr_regcap},
     {"tsqr_max_m", "BSP_TSQR_MAX_M", &Options::tsqr_max_m}, {"sb16_rows", "BSP_SB16_ROWS", &Options::sb16_rows},
-    {"route", "BSP_ROUTE", &Options::route}, {"cw_onediv", "BSP_CW_ONEDIV", &Options::cw_onediv}, {"cw_items4", "BSP_CW_ITEMS4", &Options::cw_items4}, {"cw_nw", "BSP_CW_NW", &Options::cw_nw}, {"cw_ldspad", "BSP_CW_LDSPAD", &Options::cw_ldspad}, {"cw_ipw", "BSP_CW_IPW", &Options::cw_ipw}, {"cw_band8", "BSP_CW_BAND8", &Options::cw_band8}, {"cw_split", "BSP_CW_SPLIT", &Options::cw_split}, {"cw_diag", "BSP_CW_DIAG", &Options::cw_diag}, {"s_overlap", "BSP_S_OVERLAP", &Options::s_overlap}, {"cw_streams", "BSP_CW_STREAMS", &Options::cw_streams}, {"sb8_wgs", "BSP_SB8_WGS", &Options::sb8_wgs},
+    {"route", "BSP_ROUTE", &Options::route}, {"cw_onediv", "BSP_CW_ONEDIV", &Options::cw_onediv}, {"cw_items4", "BSP_CW_ITEMS4", &Options::cw_items4}, {"cw_nw", "BSP_CW_NW", &Options::cw_nw}, {"cw_ldspad", "BSP_CW_LDSPAD", &Options::cw_ldspad}, {"cw_ipw", "BSP_CW_IPW", &Options::cw_ipw}, {"cw_band8", "BSP_CW_BAND8", &Options::cw_band8}, {"cw_split", "BSP_CW_SPLIT", &Options::cw_split}, {"cw_diag", "BSP_CW_DIAG", &Options::cw_diag}, {"s_overlap", "BSP_S_OVERLAP", &Options::s_overlap}, {"cw_streams", "BSP_CW_STREAMS", &Options::cw_streams}, {"cw_chunk_min", "BSP_CW_CHUNK_MIN", &Options::cw_chunk_min}, {"sb8_wgs", "BSP_SB8_WGS", &Options::sb8_wgs},
     {"fused_probe", "BSP_FUSED_PROBE", &Options::fused_probe},
 };
 }  // namespace
@@ -224,7 +224,7 @@ extern "C" void bspatom_problem_destroy(bspatom_problem *p)
     if (p->evx) hipEventDestroy(p->evx);
     if (p->stS) hipStreamDestroy(p->stS);
     if (p->evS) hipEventDestroy(p->evS);
-    if (p->evP) hipEventDestroy(p->evP);
+    for (hipEvent_t e : p->evC) if (e) hipEventDestroy(e);
     for (auto &e : p->ev) if (e) hipEventDestroy(e);
     if (p->st) hipStreamDestroy(p->st);
     delete p;
@@ -464,7 +464,7 @@ int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const d
         CrawfordWork cw;
         crawford_carve(b.cwork, n, k, nl, &cw);
         if (ev) BSP_HIP(hipEventRecord(ev[1], st));
-        if ((rc = crawford_run(n, npad, k, nl, d_SB, d_HB, cw, b.AB, st, s_prepared))) return rc;
+        if ((rc = crawford_run(n, npad, k, nl, d_SB, d_HB, cw, b.AB, st, s_prepared, b.s_events))) return rc;
         if (ev) BSP_HIP(hipEventRecord(ev[2], st));
         if ((rc = launch_sb16st(n, npad, nl, b.AB, b.d, b.e, st, b.status, b.sbctl, opts().cw_band8 ? 8 : 16))) return rc;
         if (ev) BSP_HIP(hipEventRecord(ev[3], st));
@@ -535,21 +535,19 @@ static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, dou
         if (!p->stS) {
             BSP_HIP(hipStreamCreateWithFlags(&p->stS, hipStreamNonBlocking));
             BSP_HIP(hipEventCreateWithFlags(&p->evS, hipEventDisableTiming));
-            BSP_HIP(hipEventCreateWithFlags(&p->evP, hipEventDisableTiming));
+            for (hipEvent_t &e : p->evC) BSP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
         if ((rc = enqueue_assemble(p, l0, 1))) return rc;
         BSP_HIP(hipEventRecord(p->evS, p->st));
         BSP_HIP(hipStreamWaitEvent(p->stS, p->evS, 0));
         CrawfordWork cw;
         crawford_carve(p->d_cwork, n, h.k, nl, &cw);
-        if ((rc = crawford_prepare(n, h.k, p->d_SB, cw, p->stS))) return rc;
-        BSP_HIP(hipEventRecord(p->evP, p->stS));
+        if ((rc = crawford_prepare(n, h.k, p->d_SB, cw, p->stS, p->evC))) return rc;   // the reduction waits for the chunks as it needs them
         if ((rc = enqueue_assemble(p, l0, nl, 1, p->d_UB))) return rc;
-        BSP_HIP(hipStreamWaitEvent(p->st, p->evP, 0));
         s_prepared = true;
     } else if ((rc = enqueue_assemble(p, l0, nl))) return rc;
     BSP_HIP(hipEventRecord(p->ev[1], p->st));
-    PipeBufs pb{p->d_UB, p->d_rdiag, p->d_Y, p->d_C, p->d_AB, p->d_d, p->d_e, p->d_work, p->d_info, p->d_status, p->d_sbctl, p->d_cwork};
+    PipeBufs pb{p->d_UB, p->d_rdiag, p->d_Y, p->d_C, p->d_AB, p->d_d, p->d_e, p->d_work, p->d_info, p->d_status, p->d_sbctl, p->d_cwork, s_prepared ? p->evC : nullptr};
     double *Eout = E_dev_out ? E_dev_out : p->d_E;
     if ((rc = pipeline_enqueue(n, np, h.k, nl, p->d_SB, p->d_HB, pb, Eout, p->st, &p->ev[1], false, s_prepared))) return rc;
     // The consumed eigenvector (l_ini, n0_ini): its eigenvalue alone by multisection as soon as the tridiagonal

@@ -64,13 +64,14 @@ struct Options {
                                  // blocks the standard form writes may ever be read)
     int route = 0;               // BSP_ROUTE: 0 = by size (the band route wherever crawford_supported), 1 = dense route (standard form, sy2sb,
                                  // two-step bulge chasing: north_star's letter, and every pencil wider than 8), 2 = band route (crawford.hip:
-                                 // the pencil stays banded; band-16 chase; UNSUPPORTED where it cannot run)
+                                 // the pencil stays banded; one-column chase on tiles of 8; UNSUPPORTED where it cannot run)
     int fused_probe = 0;         // BSP_FUSED_PROBE: TIMING EXPERIMENT ONLY (wrong results): the rank-128 update runs 16 K-steps instead of 8 and
                                  // symm is not launched -- the upper bound of what a fused update + symm sweep over A22 can gain (round-3 verdict, item 1)
     int cw_items4 = 1;           // BSP_CW_ITEMS4: 1 = crawford_item4_kernel (four chase items per wave, an item per DPP row in the RQ loop),
                                  // 0 = crawford_item_kernel (one item per wave; the cross-check)
     int cw_nw = 1;               // BSP_CW_NW: waves per workgroup of crawford_item4_kernel (1 or 4; a wave never talks to another)
     int cw_streams = 2;          // BSP_CW_STREAMS: the band reduction's channels in this many groups (1 .. 4), each on a stream of its own
+    int cw_chunk_min = 1024;     // BSP_CW_CHUNK_MIN: from this many functions on, the S-only part hands its factor over in CW_CHUNKS pieces (crawford_prepare)
     int s_overlap = 1;           // BSP_S_OVERLAP: band route: the S-only part of the reduction (band Cholesky ..) on a stream of its own beside the
                                  // assembly of the H_l
     int cw_diag = 0;             // BSP_CW_DIAG: s_memtime stamps of the phases of crawford_item4_kernel's waves, averaged over a solve (stderr)
@@ -157,11 +158,13 @@ int launch_dipole_bands(int nfun, int k, int ka, int nkp, const double *d_ptab, 
 // bandchol.hip
 int launch_band_cholesky(int n, int k, const double *d_SB, double *d_UB, double *d_rdiag, int *d_info,
                          hipStream_t st);
+int launch_band_cholesky_range(int n, int k, int jstart, int jstop, const double *d_SB, double *d_UB, double *d_rdiag, int *d_info,
+                               hipStream_t st);
 int launch_band_cholesky_pair(int n, int k, int jstop, const double *d_SB, double *d_UB, double *d_rdiag, int *d_info, hipStream_t st);
 // full = 0: C's lower triangle and first block super-diagonal only (all the reduction reads); 1: the whole matrix
 int launch_standard_form(int n, int npad, int k, int nl, const double *d_HB, const double *d_UB,
                          const double *d_rdiag, double *d_Y, double *d_C, hipStream_t st, int full = 0);
-// crawford.hip: band route -- the banded pencil to a banded standard-form matrix (half-width 15) without the dense C_l
+// crawford.hip: band route -- the banded pencil to a banded standard-form matrix (half-width 8) without the dense C_l
 struct CrawfordWork {
     double *SBf, *UBf, *rdiagf;  // [2][k][n] overlap in reversed order and as it is, their Cholesky factors, [2][n] reciprocal pivots
     double *Qel, *LiB;           // [2][N][256] elimination transforms, [2][N][64] inverse diagonal blocks of L (N = ceil(n / 8))
@@ -172,9 +175,13 @@ struct CrawfordWork {
 bool crawford_supported(int n, int k);
 size_t crawford_work_bytes(int n, int k, int nl);
 void crawford_carve(void *base, int n, int k, int nl, CrawfordWork *w);
-int crawford_prepare(int n, int k, const double *d_SB, const CrawfordWork &w, hipStream_t st);   // the S-only part (run: unless s_prepared)
+// the S-only part (run: unless s_prepared).  evc (CW_CHUNKS events, or null): the factor is computed in CW_CHUNKS launches, each followed
+// by the elimination transforms of its blocks and by evc[c], so that a run given the same events starts on the first blocks while the
+// rest of the factor is still being computed (without them the caller orders the run behind the whole of it)
+constexpr int CW_CHUNKS = 4;
+int crawford_prepare(int n, int k, const double *d_SB, const CrawfordWork &w, hipStream_t st, hipEvent_t *evc = nullptr);
 int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const double *d_HB, const CrawfordWork &w, double *d_AB,
-                 hipStream_t st, bool s_prepared = false);
+                 hipStream_t st, bool s_prepared = false, hipEvent_t *evc = nullptr);
 // sy2sb.hip
 // tsqr.hip: panel factorisation on many workgroups (TSQR + Householder reconstruction), BSP_PANEL_QR=3
 long tsqr_scr_doubles(int npad);
@@ -234,6 +241,7 @@ struct PipeBufs {
     int *status = nullptr;   // device word set to a BSP_ERR_* code by kernels that detect a failure
     void *sbctl = nullptr;   // sb2st pairing/progress control block (sb2st_ctl_bytes(nl))
     void *cwork = nullptr;   // band route: crawford_work_bytes(n, k, nl); Y, C, work may be null when only that route runs
+    hipEvent_t *s_events = nullptr;   // band route, S-only part already enqueued elsewhere (s_prepared): CW_CHUNKS events, see crawford_prepare
 };
 // 1 = dense route, 2 = band route, for a pencil of this size under the current switches (BSP_ROUTE)
 int pipeline_route(int n, int k);

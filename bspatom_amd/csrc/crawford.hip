@@ -564,12 +564,12 @@ __global__ void crawford_flip_kernel(int n, int k, const double *__restrict__ SB
 // Per block j: Li = L_jj^-1, K = Li L_{j,j-1} (L = U^T from the Cholesky factor of the reversed overlap, identity beyond n),
 // LiB[j] = Li (row-major 8 x 8) and Qel[j] = [I -K^T; 0 Li^T] (row-major 16 x 16).  One wave per block.
 // blockIdx.y = which factor (0: of the reversed overlap; 1: of the overlap itself, the run from both ends only), fstride blocks apart in
-// LiB / Qel.
-__global__ __launch_bounds__(64) void crawford_setup_kernel(int n, int k, int fstride, const double *__restrict__ UB0,
+// LiB / Qel.  The grid covers the blocks jfirst .. jfirst + gridDim.x - 1 (the factor may arrive in chunks: crawford_prepare).
+__global__ __launch_bounds__(64) void crawford_setup_kernel(int n, int k, int fstride, int jfirst, const double *__restrict__ UB0,
                                                            double *__restrict__ LiB0, double *__restrict__ Qel0)
 {
     __shared__ double Ld[CB][CB + 1], M[CB][CB + 1], Li[CB][CB + 1];
-    const int j = blockIdx.x, t = threadIdx.x, r = t >> 3, c = t & 7, b = k - 1;
+    const int j = jfirst + blockIdx.x, t = threadIdx.x, r = t >> 3, c = t & 7, b = k - 1;
     const double *UBf = UB0 + (size_t)blockIdx.y * k * n;
     double *LiB = LiB0 + (size_t)blockIdx.y * fstride * CBB, *Qel = Qel0 + (size_t)blockIdx.y * fstride * 256;
     const int i = CB * j + r;
@@ -753,8 +753,8 @@ __global__ __launch_bounds__(64) void crawford_cut_prep_kernel(int N, int Nh, in
     Eall[c0 + (size_t)Nh * CBB + t] = Eall[c1 + (size_t)(Nl - 2) * CBB + (CB - 1 - c) * CB + (CB - 1 - r)];
 }
 
-// block tridiagonal (reversed order) -> lower band storage of the band-16 chase in the ORIGINAL order:
-// AB[j * 128 + d] = A(j + d, j), d = 0 .. 31 (zero beyond the half-width 15 and beyond the matrix)
+// block tridiagonal (reversed order) -> lower band storage of the one-column chase in the ORIGINAL order:
+// AB[j * 128 + d] = A(j + d, j), d = 0 .. 31 (zero beyond the half-width handed over -- 8, or 15 with BSP_CW_BAND8=0 -- and beyond the matrix)
 // What the reduction leaves is narrower than block tridiagonal: E_1 .. E_{N-2} are upper triangular -- each is the R of the last RQ
 // factorisation that touched it (item (j, s) leaves E_{p+1} = R, the next item of the sweep fills E_p again and the one after it
 // re-factors that; tools/proto_crawford.py and tests/test_host_cpu.py check it on the dense statement) -- so the matrix has
@@ -898,11 +898,14 @@ CwShape cw_shape(int n)
     c.Ns = c.split ? c.Nh + 2 : c.N;                                       // block slots of a channel of the batch
     return c;
 }
+// The factor in chunks (crawford_prepare with events): columns per chunk, a multiple of 128 (whole blocks, whole load chunks of the
+// Cholesky kernel); one chunk for the small pencils, whose whole factor takes less than a launch or two of the reduction.
+int cw_chunk_cols(int n) { return n < opts().cw_chunk_min ? n + 128 : ((n + CW_CHUNKS - 1) / CW_CHUNKS + 127) / 128 * 128; }
 }  // namespace
 
 // The part of the reduction that depends on S alone: the reversed band, its factor, the elimination transforms (the same for every
 // channel).  On its own so that the caller can run it on a stream of its own beside the assembly of the H_l, as soon as S is there.
-int crawford_prepare(int n, int k, const double *d_SB, const CrawfordWork &w, hipStream_t st)
+int crawford_prepare(int n, int k, const double *d_SB, const CrawfordWork &w, hipStream_t st, hipEvent_t *evc)
 {
     if (!crawford_supported(n, k)) return BSP_ERR_UNSUPPORTED;
     const CwShape c = cw_shape(n);
@@ -912,18 +915,31 @@ int crawford_prepare(int n, int k, const double *d_SB, const CrawfordWork &w, hi
     hipLaunchKernelGGL(crawford_flip_kernel, dim3((n * k + 255) / 256), dim3(256), 0, st, n, k, d_SB, w.SBf);
     if (c.split) {
         if ((rc = launch_band_cholesky_pair(n, k, CB * Nh, w.SBf, w.UBf, w.rdiagf, w.info, st))) return rc;
-        hipLaunchKernelGGL(crawford_setup_kernel, dim3(Nh, 2), dim3(64), 0, st, n, k, N, w.UBf, w.LiB, w.Qel);
+        hipLaunchKernelGGL(crawford_setup_kernel, dim3(Nh, 2), dim3(64), 0, st, n, k, N, 0, w.UBf, w.LiB, w.Qel);
         hipLaunchKernelGGL(crawford_cut_setup_kernel, dim3(1), dim3(64), 0, st, n, k, N, Nh, Nl, w.SBf, w.LiB, w.Qel, w.info);
+    } else if (evc) {
+        // in chunks: the same rows by the same arithmetic (a launch takes the rows before its first from the factor in memory)
+        const int cc = cw_chunk_cols(n);
+        for (int q = 0, j0 = 0; q < CW_CHUNKS; ++q, j0 += cc) {
+            if (j0 < n) {
+                const int j1 = j0 + cc < n ? j0 + cc : n, b0 = j0 / CB, b1 = j1 < n ? j1 / CB : N;
+                if ((rc = launch_band_cholesky_range(n, k, j0, j1, w.SBf, w.UBf, w.rdiagf, w.info, st))) return rc;
+                hipLaunchKernelGGL(crawford_setup_kernel, dim3(b1 - b0, 1), dim3(64), 0, st, n, k, N, b0, w.UBf, w.LiB, w.Qel);
+            }
+            BSP_HIP(hipEventRecord(evc[q], st));
+        }
     } else {
         if ((rc = launch_band_cholesky(n, k, w.SBf, w.UBf, w.rdiagf, w.info, st))) return rc;
-        hipLaunchKernelGGL(crawford_setup_kernel, dim3(N, 1), dim3(64), 0, st, n, k, N, w.UBf, w.LiB, w.Qel);
+        hipLaunchKernelGGL(crawford_setup_kernel, dim3(N, 1), dim3(64), 0, st, n, k, N, 0, w.UBf, w.LiB, w.Qel);
     }
+    if (evc && c.split)
+        for (int q = 0; q < CW_CHUNKS; ++q) BSP_HIP(hipEventRecord(evc[q], st));
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }
 
 int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const double *d_HB, const CrawfordWork &w, double *d_AB,
-                 hipStream_t st, bool s_prepared)
+                 hipStream_t st, bool s_prepared, hipEvent_t *evc)
 {
     if (!crawford_supported(n, k)) return BSP_ERR_UNSUPPORTED;
     const int N = (n + CB - 1) / CB;
@@ -940,6 +956,11 @@ int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const doubl
     int rc;
     KScope kt(KS_CRAWFORD, st);
     if (!s_prepared && (rc = crawford_prepare(n, k, d_SB, w, st))) return rc;
+    if (!s_prepared) evc = nullptr;
+    // the factor prepared elsewhere, in chunks: chunk 0 before block 0 is touched, the others in the loop below
+    const int ccb = cw_chunk_cols(n) / CB;                                 // blocks per chunk
+    int waited = 0;
+    if (evc) BSP_HIP(hipStreamWaitEvent(st, evc[0], 0));
     hipLaunchKernelGGL(crawford_init_kernel, dim3(Nproc, ny), dim3(64), 0, st, n, k, Ns, nl, N * CBB, d_HB, w.LiB, w.D, w.E);
     BSP_HIP(hipGetLastError());
     const int qstride = N * 256;
@@ -998,6 +1019,11 @@ int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const doubl
         const int jhi = (t / 2 < Nproc - 1) ? t / 2 : Nproc - 1;
         const int nch = (jhi >= jlo && jlo >= 2) ? jhi - jlo + 1 : 0;
         if (nch + (jel ? 1 : 0) == 0) continue;
+        if (evc && jel) {                                                  // the elimination of block jel reads Qel[jel]
+            const int q = jel / ccb < CW_CHUNKS - 1 ? jel / ccb : CW_CHUNKS - 1;
+            for (; waited < q; ++waited)
+                for (int g = 0; g < ngrp; ++g) BSP_HIP(hipStreamWaitEvent(g == 0 ? st : s_aux[g - 1], evc[waited + 1], 0));
+        }
         for (int g = 0; g < ngrp; ++g) {
             const int c0 = (int)((long)ny * g / ngrp), c1 = (int)((long)ny * (g + 1) / ngrp);
             wavefront(t, jlo, nch, jel, c1 - c0, c0, g == 0 ? st : s_aux[g - 1]);
@@ -1012,6 +1038,8 @@ int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const doubl
         hipEventDestroy(evf);                                              // released once the work recorded so far has passed them
         for (int g = 0; g < ngrp - 1; ++g) hipEventDestroy(evj[g]);
     }
+    if (evc)
+        for (; waited < CW_CHUNKS - 1; ++waited) BSP_HIP(hipStreamWaitEvent(st, evc[waited + 1], 0));   // (a pencil of very few blocks)
     if (split) {
         // the step at the cut, on the trailing parts (channels 0 .. nl - 1): elimination at block Nh, its fill chased to block 0
         hipLaunchKernelGGL(crawford_cut_prep_kernel, dim3(nl), dim3(64), 0, st, Ns, Nh, Nl, nl, N, w.LiB, w.D, w.E);

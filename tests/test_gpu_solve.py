@@ -746,6 +746,12 @@ def test_band_route_properties():
         Eb, info = prob.solve(0, nl)
         assert prob.route() == 2 and np.all(info == 0)
         assert np.max(np.abs(Eb - Ed)) <= 1e-13 * np.max(np.abs(Ed)), name
+        # the factor of S handed to the reduction in pieces (what the large pencils do: chunks of 128 columns here, the last one
+        # ragged or empty), and in one piece on the main stream: the same rows by the same arithmetic
+        for kw in (dict(cw_chunk_min=0), dict(s_overlap=0)):
+            with _Options(**kw):
+                E, info = prob.solve(0, nl)
+            assert np.all(info == 0) and np.array_equal(E, Eb), (name, kw)
         prob.close()
 
 
