@@ -363,8 +363,10 @@ static size_t bisect3_lds_bytes(int n, int ng)
 template <int EPT, int TPB>
 __global__ __launch_bounds__(TPB) void bisect3_kernel(int n, int ldn, const double *__restrict__ dall,
                                                      const double *__restrict__ eall, double *wall, long ldw, int tail,
-                                                     double2 *gtail, int nl, int hybrid)
+                                                     double2 *gtail, int nl, int hybrid_arg)
 {
+    // (eight eigenvalues per thread, BSP_BISECT_EPT=8, an A/B of round 1: plain bisection -- the secant rounds' state does not fit its registers)
+    const int hybrid = EPT > 4 ? 0 : hybrid_arg;
     extern __shared__ double2 sde[];
     constexpr int NG = TPB * EPT;
     constexpr int NW = TPB / 64;
@@ -372,14 +374,13 @@ __global__ __launch_bounds__(TPB) void bisect3_kernel(int n, int ldn, const doub
     const int np = (n + HW - 1) / HW * HW;
     const int nlr = nl < np ? nl : np;                 // rows 0 .. nlr live in LDS, rows nlr + 1 .. np in global memory (gtail)
     double2 *de = sde;                                 // de[i] = (d_i, e_{i-1}^2), i = 0 .. nlr
-    // the secant rounds hand at most NG / 4 brackets to the tail: a shorter list, and in its place log2 |p_n| at the first level's
-    // grid points (the same bytes: bisect3_lds_bytes)
+    // the secant rounds hand at most NG / 4 brackets to the tail: a shorter list; the rounds themselves keep their points in the same
+    // bytes (bisect3_lds_bytes: 14 NG -- a point, its log2 |p_n| and its count in 16 bits per slot; the tail 9 NG)
     const int kcap = hybrid ? NG / 4 : KC;
     double *llo = (double *)(sde + nlr + 1);           // tail list: brackets and eigenvalue numbers
     double *lhi = llo + kcap;
     int *cg = (int *)(lhi + kcap);                     // counts at the NG evaluation slots
     int *lm = cg + NG;
-    float *lfg = (float *)(lm + kcap);                 // hybrid only
     __shared__ double red[2 * NW];
     __shared__ int sK;
     const int tid = threadIdx.x;
@@ -427,21 +428,16 @@ __global__ __launch_bounds__(TPB) void bisect3_kernel(int n, int ldn, const doub
     double lo[EPT], hi[EPT];
     int clo[EPT], chi[EPT];                            // count(lo) <= m < count(hi): the bracket is ISOLATING when chi - clo = 1
     float lflo[EPT], lfhi[EPT];                        // log2 |p_n| at the ends (3e38: not known)
-    {
+    if (!hybrid) {
         // first level: NG interior points x_j = gl + (gu - gl) (j+1)/(NG+1), j = tid + TPB c
         const double w = gu - gl;
         double xg[EPT];
         int cc[EPT];
 #pragma unroll
         for (int c = 0; c < EPT; ++c) xg[c] = gl + w * ((double)(tid + TPB * c + 1) * (1.0 / (NG + 1)));
-        float lfc[EPT];
-        if (hybrid) sturm_counts3<EPT, true>(de, np, xg, cc, gt, nlr, lfc);
-        else sturm_counts3<EPT>(de, np, xg, cc, gt, nlr);
+        sturm_counts3<EPT>(de, np, xg, cc, gt, nlr);
 #pragma unroll
-        for (int c = 0; c < EPT; ++c) {
-            cg[tid + TPB * c] = cc[c];
-            if (hybrid) lfg[tid + TPB * c] = lfc[c];
-        }
+        for (int c = 0; c < EPT; ++c) cg[tid + TPB * c] = cc[c];
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < EPT; ++c) {
@@ -455,8 +451,6 @@ __global__ __launch_bounds__(TPB) void bisect3_kernel(int n, int ldn, const doub
             hi[c] = (R >= NG) ? gu : gl + w * ((double)(R + 1) * (1.0 / (NG + 1)));
             clo[c] = (L < 0) ? 0 : cg[L];
             chi[c] = (R >= NG) ? n : cg[R];
-            lflo[c] = (hybrid && L >= 0) ? lfg[L] : 3e38f;
-            lfhi[c] = (hybrid && R < NG) ? lfg[R] : 3e38f;
         }
     }
     bool done[EPT];
@@ -470,42 +464,72 @@ __global__ __launch_bounds__(TPB) void bisect3_kernel(int n, int ldn, const doub
         // them are followed by a bisection, and the stopping rule is the bisection's: the result is a point of a bracket
         // narrower than 2 eps |x|, as before -- after ~19 evaluations instead of ~49 (tools/sim_secant.py on C4's spectra: 99 %
         // within 25; single precision in log2 |p_n| costs nothing).
+        //
+        // SHARED POINTS: while a bracket still holds several eigenvalues of this workgroup -- numbers a .. b - 1, q = b - a of them;
+        // they all carry the same bracket -- eigenvalue a + r takes point r + 1 of q + 1 equal parts of it, every point of the round
+        // goes to LDS with its count and its log2 |p_n| (slot = eigenvalue number, so a bracket's points are the slots a .. b - 1, in
+        // ascending order), and every one of the q eigenvalues takes the tightest bracket that ALL q counts allow: the bracket
+        // shrinks q + 1 fold where the midpoint halved it.  The first level (everything in the Gershgorin interval: a uniform grid
+        // of NG points) is the first round of the same rule; on the graded spectra of the B-spline pencils, where a tenth of that
+        // grid's cells hold all the eigenvalues, the next two rounds do what took ten bisections (tools/sim_grid.py: 11 - 15
+        // evaluations per eigenvalue instead of 17 - 19).  Any point with count <= m is a lower end for eigenvalue m and any with
+        // count > m an upper end, whoever evaluated it: nothing rests on the brackets of a cell being the same or on the counts
+        // being monotone -- a point is taken if it lies strictly inside the bracket the eigenvalue's OWN point has left.
+        double *xs = llo;                              // the round's points, by slot (the tail's list and counts reuse the bytes)
+        float *lfs = (float *)(xs + NG);
+        unsigned short *cs = (unsigned short *)(lfs + NG);       // n <= 65535 (launch_bisect)
+        const int m0 = blockIdx.x * NG, m1 = min(m0 + NG, n);
         float wref[EPT];                              // the bracket's width when it last halved
         int st[EPT];                                  // bits 0-1: the end the last estimate replaced (1 hi, 2 lo); bits 2..: rounds since wref
 #pragma unroll
-        for (int c = 0; c < EPT; ++c) { wref[c] = 3e38f; st[c] = 0; }
+        for (int c = 0; c < EPT; ++c) {
+            wref[c] = 3e38f; st[c] = 0;
+            lo[c] = gl; hi[c] = gu; clo[c] = 0; chi[c] = n; lflo[c] = 3e38f; lfhi[c] = 3e38f;
+        }
         for (int it = 0; it < 200; ++it) {
             double x[EPT];
             bool sec[EPT];
+            int rng[EPT];                             // shared point: slots s0 | s1 << 16 of the bracket's points, else 0
 #pragma unroll
             for (int c = 0; c < EPT; ++c) {
+                const int m = mbase + TPB * c;
                 const double wd = hi[c] - lo[c];
-                done[c] = (mbase + TPB * c >= n) || bracket_final(lo[c], hi[c]);
+                done[c] = (m >= n) || bracket_final(lo[c], hi[c]);
                 if ((float)wd <= 0.5f * wref[c]) { wref[c] = (float)wd; st[c] &= 3; }
                 const bool slow = (st[c] >> 2) >= 3;
                 st[c] += 4;
-                x[c] = 0.5 * (lo[c] + hi[c]); sec[c] = false;
+                x[c] = 0.5 * (lo[c] + hi[c]); sec[c] = false; rng[c] = 0;
+                const int a = max(clo[c], m0), b = min(chi[c], m1);
                 if (chi[c] - clo[c] == 1 && lflo[c] < 1e38f && lfhi[c] < 1e38f && !slow && !done[c]) {
                     const double tiny = 2.0 * 2.220446049250313e-16 * fmax(fabs(lo[c]), fabs(hi[c]));
                     const float dl = fminf(fmaxf(lflo[c] - lfhi[c], -60.0f), 60.0f);
                     const double r = (double)exp2f(dl);
                     const double xe = fmin(fmax(lo[c] + wd * (r / (1.0 + r)), lo[c] + tiny), hi[c] - tiny);
                     if (xe > lo[c] && xe < hi[c]) { x[c] = xe; sec[c] = true; }
+                } else if (b - a > 1 && m >= a && m < b && !slow && !done[c]) {
+                    const double xq = msect_point(lo[c], wd, m - a, 1.0 / (double)(b - a + 1));
+                    if (xq > lo[c] && xq < hi[c]) { x[c] = xq; rng[c] = (a - m0) | ((b - m0) << 16); }
                 }
             }
             // on to the multisection tail once few enough brackets are left for it to have many points in each (NG / hybrid slots:
             // the stragglers of these rounds are brackets that are still WIDE, and the tail shrinks a bracket by P + 1 per round)
             int tot = 0;
 #pragma unroll
-            for (int c = 0; c < EPT; ++c) tot += __syncthreads_count(!done[c]);
+            for (int c = 0; c < EPT; ++c) tot += __syncthreads_count(!done[c]);     // (and: last round's reads of xs, cs, lfs are over)
             if (tot <= (tail ? NG / hybrid : 0)) break;
             int cnt[EPT];
             float lf[EPT];
             sturm_counts3<EPT, true>(de, np, x, cnt, gt, nlr, lf);
 #pragma unroll
             for (int c = 0; c < EPT; ++c) {
+                xs[tid + TPB * c] = x[c]; cs[tid + TPB * c] = (unsigned short)cnt[c]; lfs[tid + TPB * c] = lf[c];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < EPT; ++c) {
                 if (done[c]) continue;
-                const bool up = cnt[c] > mbase + TPB * c;                      // x is above eigenvalue m: it replaces hi
+                const int m = mbase + TPB * c;
+                const bool up = cnt[c] > m;                                    // x is above eigenvalue m: it replaces hi
                 const int last = st[c] & 3;
                 if (up) {
                     hi[c] = x[c]; chi[c] = cnt[c]; lfhi[c] = lf[c];
@@ -515,8 +539,21 @@ __global__ __launch_bounds__(TPB) void bisect3_kernel(int n, int ldn, const doub
                     if (sec[c] && last == 2 && lfhi[c] < 1e38f) lfhi[c] -= 1.0f;
                 }
                 st[c] = (st[c] & ~3) | (sec[c] ? (up ? 1 : 2) : 0);
+                if (rng[c]) {
+                    // the other points of the bracket: L = the last slot before R with count <= m, R = the first found with count > m
+                    // (the search's own tests guarantee both counts; -1 / s1: none)
+                    const int s0 = rng[c] & 0xffff, s1 = rng[c] >> 16;
+                    int L = s0 - 1, R = s1;
+                    while (R - L > 1) {
+                        const int mid = (L + R) >> 1;
+                        if ((int)cs[mid] > m) R = mid; else L = mid;
+                    }
+                    if (R < s1) { const double xr = xs[R]; if (xr > lo[c] && xr < hi[c]) { hi[c] = xr; chi[c] = cs[R]; lfhi[c] = lfs[R]; } }
+                    if (L >= s0) { const double xl = xs[L]; if (xl > lo[c] && xl < hi[c]) { lo[c] = xl; clo[c] = cs[L]; lflo[c] = lfs[L]; } }
+                }
             }
         }
+        __syncthreads();                               // the tail's list goes where the points were
     } else
     // lock-step bisection until every thread has at most EPT/2 unfinished eigenvalues (<= KC in the workgroup)
     for (int it = 0; it < 160; ++it) {
@@ -846,7 +883,9 @@ int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_
     else if (variant == 2) hipLaunchKernelGGL(bisect2_kernel, grid, dim3(256), lds, st, n, ldn, d_d, d_e, d_w, ldw);
     else {
         const dim3 g3((n + ng - 1) / ng, batch);
-        const int tail = opts().bisect_tail, hyb = opts().bisect_secant == 1 ? 8 : (opts().bisect_secant >= 4 ? opts().bisect_secant : (opts().bisect_secant >= 2 ? 4 : 0));
+        const int tail = opts().bisect_tail;
+        // (the secant rounds keep a point's count in 16 bits: beyond that size plain bisection)
+        const int hyb = n > 65535 ? 0 : (opts().bisect_secant == 1 ? 8 : (opts().bisect_secant >= 4 ? opts().bisect_secant : (opts().bisect_secant >= 2 ? 4 : 0)));
         if (mode == 512) hipLaunchKernelGGL((bisect3_kernel<4, 512>), g3, dim3(512), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail, gtail, nl, hyb);
         else if (mode == 1024) hipLaunchKernelGGL((bisect3_kernel<2, 1024>), g3, dim3(1024), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail, gtail, nl, hyb);
         else if (mode == 8) hipLaunchKernelGGL((bisect3_kernel<8, 256>), g3, dim3(256), lds3, st, n, ldn, d_d, d_e, d_w, ldw, tail, gtail, nl, hyb);
