@@ -33,8 +33,8 @@ class Sizes(C.Structure):
 
 EXPORTS = ["bspatom_input_defaults", "bspatom_device_count", "bspatom_host_setup", "bspatom_problem_create", "bspatom_problem_destroy",
            "bspatom_problem_sizes", "bspatom_problem_grid", "bspatom_problem_route", "bspatom_assemble", "bspatom_solve", "bspatom_solve_dev",
-           "bspatom_eigvec", "bspatom_eigvecs", "bspatom_dipole_bands", "bspatom_dipole_elements", "bspatom_write_wf", "bspatom_last_timing", "bsp_dsygv_", "bspatom_stage_gemm",
-           "bspatom_stage_standard_form", "bspatom_stage_sy2sb", "bspatom_stage_panel", "bspatom_stage_sb2st", "bspatom_stage_sb2sb", "bspatom_stage_bisect", "bspatom_stage_crawford",
+           "bspatom_eigvec", "bspatom_eigvecs", "bspatom_dipole_bands", "bspatom_dipole_elements", "bspatom_write_wf", "bspatom_last_timing", "bspatom_early_vector_state", "bsp_dsygv_", "bspatom_stage_gemm",
+           "bspatom_stage_standard_form", "bspatom_stage_sy2sb", "bspatom_stage_panel", "bspatom_stage_sb2st", "bspatom_stage_sb2sb", "bspatom_stage_bisect", "bspatom_stage_crawford", "bspatom_stage_band_eigenvalue",
            "bspatom_release_scratch", "bspatom_run_token", "bspatom_comm_create", "bspatom_comm_allgather", "bspatom_comm_collectives", "bspatom_comm_destroy",
            "bspatom_set_option", "bspatom_get_option", "bspatom_kernel_times", "bspatom_kernel_slot_name"]
 
@@ -67,6 +67,7 @@ def lib():
         L.bspatom_dipole_bands.argtypes = [vp, vp]
         L.bspatom_write_wf.argtypes = [vp, vp, i32, vp, vp]
         L.bspatom_last_timing.argtypes = [vp, vp]
+        L.bspatom_early_vector_state.argtypes = [vp, vp]
         L.bspatom_stage_gemm.argtypes = [i32, i32, i32, i32, vp, lng, lng, lng, lng, vp, lng, lng, lng, lng,
                                          vp, lng, lng, lng, lng, dbl, dbl]
         L.bspatom_stage_standard_form.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp]
@@ -76,6 +77,7 @@ def lib():
         L.bspatom_stage_sb2sb.argtypes = [i32, i32, i32, vp]
         L.bspatom_stage_bisect.argtypes = [i32, i32, vp, vp, vp]
         L.bspatom_stage_crawford.argtypes = [i32, i32, i32, vp, vp, vp, vp]
+        L.bspatom_stage_band_eigenvalue.argtypes = [i32, i32, vp, vp, i32, vp]
         L.bsp_dsygv_.restype = None
         L.bspatom_set_option.argtypes = [C.c_char_p, i32]
         L.bspatom_get_option.argtypes = [C.c_char_p, C.POINTER(i32)]
@@ -193,6 +195,12 @@ class Problem:
         _chk(lib().bspatom_write_wf(self._h, _p(c), npts, _p(r), _p(u)), "bspatom_write_wf")
         return r, u
 
+    def early_vector_state(self):
+        """0: the last solve computed no early vector; 1: computed and kept; -1: computed, failed its check, dropped (include/bspatom.h)."""
+        st = C.c_int32(0)
+        _chk(lib().bspatom_early_vector_state(self._h, C.byref(st)), "bspatom_early_vector_state")
+        return st.value
+
     def route(self):
         """2 = band route (csrc/crawford.hip), 1 = dense route: what solve() takes under the current switches"""
         r = lib().bspatom_problem_route(self._h)
@@ -287,6 +295,15 @@ def stage_crawford(SB, HB):
     _chk(lib().bspatom_stage_crawford(n, k, nl, _p(np.ascontiguousarray(SB, dtype=np.float64)),
                                       _p(np.ascontiguousarray(HB, dtype=np.float64)), _p(AB), C.byref(info)), "bspatom_stage_crawford")
     return AB, info.value
+
+
+def stage_band_eigenvalue(SB, HB, m):
+    """Eigenvalue m (0-based, ascending) of the banded pencil (HB, SB) (upper bands (k, n)) from inertia counts (csrc/bandsect.hip)."""
+    k, n = HB.shape
+    lam = np.zeros(1)
+    _chk(lib().bspatom_stage_band_eigenvalue(n, k, _p(np.ascontiguousarray(SB, dtype=np.float64)),
+                                             _p(np.ascontiguousarray(HB, dtype=np.float64)), m, _p(lam)), "bspatom_stage_band_eigenvalue")
+    return lam[0]
 
 
 def stage_bisect(d, e):

@@ -38,6 +38,7 @@ struct bspatom_problem {
     hipEvent_t evx = nullptr;
     hipStream_t stS = nullptr;                // band route: the S-only part of the reduction beside the assembly of the H_l
     hipEvent_t evS = nullptr, evC[bsp::CW_CHUNKS] = {};
+    bool pre_early = false, pre_early_ok = false;   // the prefetched vector's eigenvalue came from the pencil (bandsect.hip); it passed the check
     double *d_pvec = nullptr, *d_pE = nullptr;
     int *d_pinfo = nullptr;
     int pre_l = -1, pre_n0 = -1, pre_ch = 0;
@@ -76,7 +77,7 @@ const OptName OPT_TABLE[] = {
     {"sy2sb_segs", "BSP_SY2SB_SEGS", &Options::sy2sb_segs}, {"panel_qr", "BSP_PANEL_QR", &Options::panel_qr},
     {"gemm_diag", "BSP_GEMM_DIAG", &Options::gemm_diag}, {"bisect", "BSP_BISECT", &Options::bisect},
     {"bisect_ept", "BSP_BISECT_EPT", &Options::bisect_ept},
-    {"bisect_tail", "BSP_BISECT_TAIL", &Options::bisect_tail}, {"bisect_secant", "BSP_BISECT_SECANT", &Options::bisect_secant}, {"no_eigvec_prefetch", "BSP_NO_EIGVEC_PREFETCH", &Options::no_eigvec_prefetch},
+    {"bisect_tail", "BSP_BISECT_TAIL", &Options::bisect_tail}, {"bisect_secant", "BSP_BISECT_SECANT", &Options::bisect_secant}, {"no_eigvec_prefetch", "BSP_NO_EIGVEC_PREFETCH", &Options::no_eigvec_prefetch}, {"vec_early", "BSP_VEC_EARLY", &Options::vec_early}, {"vec_own_cu", "BSP_VEC_OWN_CU", &Options::vec_own_cu},
     {"poison_c", "BSP_POISON_C", &Options::poison_c}, {"sb2sb_mfma", "BSP_SB2SB_MFMA", &Options::sb2sb_mfma},
     {"ktime", "BSP_KTIME", &Options::ktime}, {"tsqr_regcap", "BSP_TSQR_REGCAP", &Options::tsqr_regcap},
     {"tsqr_max_m", "BSP_TSQR_MAX_M", &Options::tsqr_max_m}, {"sb16_rows", "BSP_SB16_ROWS", &Options::sb16_rows},
@@ -464,8 +465,9 @@ int pipeline_enqueue(int n, int npad, int k, int nl, const double *d_SB, const d
         CrawfordWork cw;
         crawford_carve(b.cwork, n, k, nl, &cw);
         if (ev) BSP_HIP(hipEventRecord(ev[1], st));
-        if ((rc = crawford_run(n, npad, k, nl, d_SB, d_HB, cw, b.AB, st, s_prepared, b.s_events))) return rc;
+        if ((rc = crawford_run(n, npad, k, nl, d_SB, d_HB, cw, b.AB, st, s_prepared, b.s_events, b.aux0))) return rc;
         if (ev) BSP_HIP(hipEventRecord(ev[2], st));
+        if (b.chase_after) BSP_HIP(hipStreamWaitEvent(st, b.chase_after, 0));
         if ((rc = launch_sb16st(n, npad, nl, b.AB, b.d, b.e, st, b.status, b.sbctl, opts().cw_band8 ? 8 : 16))) return rc;
         if (ev) BSP_HIP(hipEventRecord(ev[3], st));
         if (!with_bisect) return BSP_OK;
@@ -547,14 +549,16 @@ static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, dou
         s_prepared = true;
     } else if ((rc = enqueue_assemble(p, l0, nl))) return rc;
     BSP_HIP(hipEventRecord(p->ev[1], p->st));
-    PipeBufs pb{p->d_UB, p->d_rdiag, p->d_Y, p->d_C, p->d_AB, p->d_d, p->d_e, p->d_work, p->d_info, p->d_status, p->d_sbctl, p->d_cwork, s_prepared ? p->evC : nullptr};
-    double *Eout = E_dev_out ? E_dev_out : p->d_E;
-    if ((rc = pipeline_enqueue(n, np, h.k, nl, p->d_SB, p->d_HB, pb, Eout, p->st, &p->ev[1], false, s_prepared))) return rc;
-    // The consumed eigenvector (l_ini, n0_ini): its eigenvalue alone by multisection as soon as the tridiagonal
-    // matrices exist (ev[4] = after sb2st), then the inverse iteration, on a second stream beside the batched bisection.
-    p->pre_l = -1;
+    // The consumed eigenvector (l_ini, n0_ini).  Band route (BSP_VEC_EARLY): its eigenvalue from the PENCIL, by multisection on the
+    // inertia of H - x S (bandsect.hip), as soon as the channel is assembled, the inverse iteration behind it, both on a side stream
+    // beside the reductions -- the vector is there long before the spectra, and checked against them below.  Otherwise: the
+    // eigenvalue alone by multisection as soon as the tridiagonal matrices exist, then the inverse iteration on the side stream
+    // beside the batched bisection.
+    p->pre_l = -1; p->pre_early = false;
     const int tl = h.in.l_ini, tn0 = h.in.n0_ini;
-    if (tl >= l0 && tl < l0 + nl && tn0 >= 1 && tn0 <= n && !opts().no_eigvec_prefetch) {
+    const bool want_vec = tl >= l0 && tl < l0 + nl && tn0 >= 1 && tn0 <= n && !opts().no_eigvec_prefetch;
+    const bool early = want_vec && route == 2 && opts().vec_early;
+    auto side_stream = [&]() -> int {
         if (!p->st2) {
             BSP_HIP(hipStreamCreateWithFlags(&p->st2, hipStreamNonBlocking));
             BSP_HIP(hipEventCreateWithFlags(&p->evx, hipEventDisableTiming));
@@ -562,13 +566,37 @@ static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, dou
             BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_pE), sizeof(double)));
             BSP_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_pinfo), sizeof(int)));
         }
-        if ((rc = ensure_vec_scratch(p))) return rc;
+        return ensure_vec_scratch(p);
+    };
+    if (early) {
+        if ((rc = side_stream())) return rc;
         p->pre_ch = tl - l0;                               // member: must outlive the asynchronous copy
+        // on the stream that prepared S, if there is one, behind that (it has nothing else to do; with a stream more -- the main one,
+        // this one, the reduction's second group's and a fourth -- two of them share a hardware queue: the reduction's second group
+        // then waited behind these 20 ms, measured, 28 -> 44 ms; and the second group on THIS stream starts 1.5 ms late: 28 -> 31 ms)
+        hipStream_t sv = s_prepared ? p->stS : p->st2;
+        BSP_HIP(hipMemsetAsync(p->d_pinfo, 0, sizeof(int), sv));
+        if (s_prepared && tl == l0) BSP_HIP(hipStreamWaitEvent(sv, p->evS, 0));     // its channel was assembled first, S with it
+        else {
+            BSP_HIP(hipEventRecord(p->evx, p->st));        // the bands are assembled
+            BSP_HIP(hipStreamWaitEvent(sv, p->evx, 0));
+        }
+        if ((rc = launch_early_vector(n, h.k, p->d_SB, p->d_HB + (size_t)p->pre_ch * h.k * n, tn0 - 1, p->d_pE, p->d_vwork, p->d_pvec,
+                                      p->d_pinfo, sv, opts().vec_own_cu != 0))) return rc;
+        BSP_HIP(hipEventRecord(p->evx, sv));
+        p->pre_l = tl; p->pre_n0 = tn0; p->pre_early = true;
+    }
+    PipeBufs pb{p->d_UB, p->d_rdiag, p->d_Y, p->d_C, p->d_AB, p->d_d, p->d_e, p->d_work, p->d_info, p->d_status, p->d_sbctl, p->d_cwork, s_prepared ? p->evC : nullptr,
+                nullptr, (early && opts().vec_early == 3) ? p->evx : nullptr};
+    double *Eout = E_dev_out ? E_dev_out : p->d_E;
+    if ((rc = pipeline_enqueue(n, np, h.k, nl, p->d_SB, p->d_HB, pb, Eout, p->st, &p->ev[1], false, s_prepared))) return rc;
+    if (want_vec && !early) {
+        if ((rc = side_stream())) return rc;
+        p->pre_ch = tl - l0;
         const int ch = p->pre_ch;
         // The eigenvalue first, ALONE on the main stream (one workgroup, six multisection rounds: ~1 ms on the idle
         // GPU; beside the batched bisection it ran 7-13 ms, sharing a CU or waiting for one), then the inverse
-        // iteration on the side stream beside the batched bisection -- the batched kernel leaves LDS for it when it
-        // runs eight eigenvalues per thread (launch_bisect).  Kernel trace before: spectra at +16 ms after the bulge
+        // iteration on the side stream beside the batched bisection.  Kernel trace before: spectra at +16 ms after the bulge
         // chasing, eigenvector at +30 ms.
         BSP_HIP(hipMemcpyAsync(p->d_chan, &p->pre_ch, sizeof(int), hipMemcpyHostToDevice, p->st));
         BSP_HIP(hipMemsetAsync(p->d_pinfo, 0, sizeof(int), p->st));
@@ -599,6 +627,24 @@ static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, dou
     hipEventElapsedTime(&tot, p->ev[0], p->ev[5]);
     p->ms[5] = tot;
     if ((rc = check_status(p))) return rc;
+    if (p->pre_early) {
+        // the early vector's eigenvalue came from inertia counts without pivoting: it must be eigenvalue tn0 of the spectra just
+        // computed -- within 1e-10 of the spectrum's width, and no other eigenvalue nearer -- or the vector is forgotten
+        // (bspatom_eigvec then takes the eigenvalue from the spectra, as for every other vector)
+        const int m = tn0 - 1, i0 = m > 0 ? m - 1 : 0, i1 = m < n - 1 ? m + 1 : n - 1;
+        double ev[3] = {0, 0, 0}, lb = 0, ends[2];
+        const double *Erow = p->d_E + (size_t)p->pre_ch * n;
+        BSP_HIP(hipMemcpy(ev, Erow + i0, (size_t)(i1 - i0 + 1) * sizeof(double), hipMemcpyDeviceToHost));
+        BSP_HIP(hipMemcpy(&ends[0], Erow, sizeof(double), hipMemcpyDeviceToHost));
+        BSP_HIP(hipMemcpy(&ends[1], Erow + n - 1, sizeof(double), hipMemcpyDeviceToHost));
+        BSP_HIP(hipMemcpy(&lb, p->d_pE, sizeof(double), hipMemcpyDeviceToHost));
+        const double width = fmax(fabs(ends[0]), fabs(ends[1])), em = ev[m - i0], dist = fabs(lb - em);
+        bool ok = dist <= 1e-10 * width;
+        for (int i = i0; i <= i1; ++i)
+            if (i != m && fabs(lb - ev[i - i0]) < dist) ok = false;
+        if (!ok || opts().vec_early == 2) p->pre_l = -1;     // (2: the check fails on purpose -- the fallback's test)
+        p->pre_early_ok = ok;
+    }
     int cinfo = 0;
     if (route == 2) {
         // The band route factors the REVERSED overlap.  If that broke down, S is not positive definite: DSYGV's info names the
@@ -630,6 +676,13 @@ extern "C" int bspatom_solve_dev(bspatom_problem *p, int l0, int nl, double *E_d
 {
     if (!E_dev) return BSP_ERR_ARG;
     return solve_impl(p, l0, nl, E_dev, nullptr, info);
+}
+
+extern "C" int bspatom_early_vector_state(const bspatom_problem *p, int32_t *state)
+{
+    if (!p || !state) return BSP_ERR_ARG;
+    *state = !p->pre_early ? 0 : (p->pre_early_ok ? 1 : -1);
+    return BSP_OK;
 }
 
 extern "C" int bspatom_last_timing(const bspatom_problem *p, double ms[6])
@@ -957,6 +1010,18 @@ extern "C" int bspatom_stage_crawford(int n, int k, int nl, const double *SB, co
         BSP_HIP(hipMemcpy(AB + (size_t)b * npad * 128, dAB.p + b * ab_stride(npad), (size_t)npad * 128 * sizeof(double),
                           hipMemcpyDeviceToHost));
     return BSP_OK;
+}
+
+extern "C" int bspatom_stage_band_eigenvalue(int n, int k, const double *SB, const double *HB, int m, double *lambda)
+{
+    int rc;
+    if ((rc = need_gpu())) return rc;
+    if (!SB || !HB || !lambda || n < 1) return BSP_ERR_ARG;
+    DevBuf dS, dH, dl;
+    if ((rc = dS.put(SB, (size_t)k * n)) || (rc = dH.put(HB, (size_t)k * n)) || (rc = dl.alloc(1))) return rc;
+    if ((rc = launch_band_multisect(n, k, dS.p, dH.p, m, dl.p, 0))) return rc;
+    BSP_HIP(hipDeviceSynchronize());
+    return dl.get(lambda, 1);
 }
 
 extern "C" int bspatom_stage_bisect(int n, int batch, const double *d, const double *e, double *w)

@@ -57,6 +57,8 @@ struct Options {
                                  // fraction of a workgroup's 1024 eigenvalues (1 / value) left to the multisection tail (1 = 8)
     int bisect_tail = 1;         // BSP_BISECT_TAIL: 0 = lock-step bisection to the end (no multisection tail), for A/B timing
     int no_eigvec_prefetch = 0;
+    int vec_early = 1;           // BSP_VEC_EARLY: band route, the consumed eigenvector's eigenvalue from the pencil's inertia right after the assembly (bandsect.hip); 0: from the tridiagonal matrix at the end; 2: as 1 with the check made to fail
+    int vec_own_cu = 1;          // BSP_VEC_OWN_CU: the early vector's workgroup asks for a CU's whole LDS (eigvec.hip::early_vector_kernel)
     int sb2sb_mfma = 1;          // 1: block-chasing item on the matrix cores (sbr2.hip); 0: the first, all-VALU kernel (cross-check)
     int sb16_rows = 1;           // BSP_SB16_ROWS: 1 = band 16 -> 1 with a whole chase item per DPP row, four sweeps per wave (sbr2.hip); 0 = the
                                  // first layout (one tile spread over a wave), kept as the cross-check
@@ -181,7 +183,7 @@ void crawford_carve(void *base, int n, int k, int nl, CrawfordWork *w);
 constexpr int CW_CHUNKS = 4;
 int crawford_prepare(int n, int k, const double *d_SB, const CrawfordWork &w, hipStream_t st, hipEvent_t *evc = nullptr);
 int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const double *d_HB, const CrawfordWork &w, double *d_AB,
-                 hipStream_t st, bool s_prepared = false, hipEvent_t *evc = nullptr);
+                 hipStream_t st, bool s_prepared = false, hipEvent_t *evc = nullptr, hipStream_t aux0 = nullptr);
 // sy2sb.hip
 // tsqr.hip: panel factorisation on many workgroups (TSQR + Householder reconstruction), BSP_PANEL_QR=3
 long tsqr_scr_doubles(int npad);
@@ -220,6 +222,13 @@ int launch_sb2st(int n, int npad, int b, int batch, double *d_AB, double *d_d, d
 int launch_bisect(int n, int ldn, int batch, const double *d_d, const double *d_e, double *d_w,
                   long ldw, hipStream_t st);
 int launch_bisect_one(int n, const double *d_d, const double *d_e, int m, double *d_out, hipStream_t st);
+// bandsect.hip: eigenvalue m (0-based, ascending) of the banded pencil itself (upper bands, k - 1 <= 8), one workgroup
+int launch_band_multisect(int n, int k, const double *d_SB, const double *d_HB, int m, double *d_out, hipStream_t st);
+// eigvec.hip: that eigenvalue and its eigenvector in one launch of one workgroup (d_HB: the channel's own band; d_work: invit_work_doubles
+// for one vector).  own_cu: the workgroup asks for OWN_CU_LDS bytes of LDS, so that nothing of the band route's kernels fits beside it
+constexpr size_t OWN_CU_LDS = 144 * 1024;           // of 160 KB: 16 KB left
+int launch_early_vector(int n, int k, const double *d_SB, const double *d_HB, int m, double *d_E, double *d_work, double *d_vec,
+                        int *d_info, hipStream_t st, bool own_cu);
 // eigvec.hip
 // vector iv: channel chan[iv] of HB (HB + chan*k*n), eigenvalue E[iv]; work: nvec*invit_work_doubles
 int launch_inverse_iteration(int n, int k, int nvec, const double *d_SB, const double *d_HB,
@@ -242,6 +251,8 @@ struct PipeBufs {
     void *sbctl = nullptr;   // sb2st pairing/progress control block (sb2st_ctl_bytes(nl))
     void *cwork = nullptr;   // band route: crawford_work_bytes(n, k, nl); Y, C, work may be null when only that route runs
     hipEvent_t *s_events = nullptr;   // band route, S-only part already enqueued elsewhere (s_prepared): CW_CHUNKS events, see crawford_prepare
+    hipStream_t aux0 = nullptr;       // band route: the caller's stream for the reduction's second group of channels (crawford_run)
+    hipEvent_t chase_after = nullptr; // band route: the chase waits for this event (the early vector's kernels hold LDS two workgroups of the chase need)
 };
 // 1 = dense route, 2 = band route, for a pencil of this size under the current switches (BSP_ROUTE)
 int pipeline_route(int n, int k);

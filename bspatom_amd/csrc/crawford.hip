@@ -537,6 +537,9 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
                                                             int nlead, const double *__restrict__ Qel, double *Dall, double *Eall, double *Gall,
                                                             unsigned long long *diag)
 {
+    // a launch waits for its slowest wave: the waves of these launches go first on a SIMD they share with the long-running single
+    // workgroups of the consumed eigenvector (bandsect.hip, eigvec.hip: priority 0), which have 60 ms to spare
+    __builtin_amdgcn_s_setprio(3);
     // BSP_CW_DIAG: s_memtime stamps of a wave's phases, summed over the waves of every launch (diag[0..6] ticks, diag[7] waves)
     if (diag && (((blockIdx.x & 7) | (blockIdx.y & 7)) != 0)) diag = nullptr;   // one wave in 64 reports (the sums are atomics)
     __shared__ __attribute__((aligned(16))) double Qs[NW][4][16 * QLD];  // per wave and item slot: Q, row-major, stride QLD
@@ -939,7 +942,7 @@ int crawford_prepare(int n, int k, const double *d_SB, const CrawfordWork &w, hi
 }
 
 int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const double *d_HB, const CrawfordWork &w, double *d_AB,
-                 hipStream_t st, bool s_prepared, hipEvent_t *evc)
+                 hipStream_t st, bool s_prepared, hipEvent_t *evc, hipStream_t aux0)
 {
     if (!crawford_supported(n, k)) return BSP_ERR_UNSUPPORTED;
     const int N = (n + CB - 1) / CB;
@@ -1002,16 +1005,20 @@ int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const doubl
         ngrp = opts().cw_streams > 4 ? 4 : opts().cw_streams;
         while (ngrp > 1 && nl / ngrp < 16) --ngrp;
     }
+    // aux0: a stream of the caller's for the second group (the one that prepared S, idle by now: a process has few hardware queues, and
+    // a stream more than those makes two of them wait for each other)
     static hipStream_t s_aux[3] = {nullptr, nullptr, nullptr};
+    hipStream_t aux[3];
     hipEvent_t evf = nullptr, evj[3] = {nullptr, nullptr, nullptr};
     if (ngrp > 1) {
         static std::mutex mx;
         std::lock_guard<std::mutex> lk(mx);
         for (int g = 0; g < ngrp - 1; ++g)
-            if (!s_aux[g]) BSP_HIP(hipStreamCreateWithFlags(&s_aux[g], hipStreamNonBlocking));
+            if (!s_aux[g] && !(g == 0 && aux0)) BSP_HIP(hipStreamCreateWithFlags(&s_aux[g], hipStreamNonBlocking));
+        for (int g = 0; g < 3; ++g) aux[g] = (g == 0 && aux0) ? aux0 : s_aux[g];
         BSP_HIP(hipEventCreateWithFlags(&evf, hipEventDisableTiming));
         BSP_HIP(hipEventRecord(evf, st));
-        for (int g = 0; g < ngrp - 1; ++g) BSP_HIP(hipStreamWaitEvent(s_aux[g], evf, 0));
+        for (int g = 0; g < ngrp - 1; ++g) BSP_HIP(hipStreamWaitEvent(aux[g], evf, 0));
     }
     for (int t = 1; t <= tmax; ++t) {
         const int jel = ((t & 1) && (t + 1) / 2 <= Nproc - 1) ? (t + 1) / 2 : 0;
@@ -1022,17 +1029,17 @@ int crawford_run(int n, int npad, int k, int nl, const double *d_SB, const doubl
         if (evc && jel) {                                                  // the elimination of block jel reads Qel[jel]
             const int q = jel / ccb < CW_CHUNKS - 1 ? jel / ccb : CW_CHUNKS - 1;
             for (; waited < q; ++waited)
-                for (int g = 0; g < ngrp; ++g) BSP_HIP(hipStreamWaitEvent(g == 0 ? st : s_aux[g - 1], evc[waited + 1], 0));
+                for (int g = 0; g < ngrp; ++g) BSP_HIP(hipStreamWaitEvent(g == 0 ? st : aux[g - 1], evc[waited + 1], 0));
         }
         for (int g = 0; g < ngrp; ++g) {
             const int c0 = (int)((long)ny * g / ngrp), c1 = (int)((long)ny * (g + 1) / ngrp);
-            wavefront(t, jlo, nch, jel, c1 - c0, c0, g == 0 ? st : s_aux[g - 1]);
+            wavefront(t, jlo, nch, jel, c1 - c0, c0, g == 0 ? st : aux[g - 1]);
         }
     }
     if (ngrp > 1) {
         for (int g = 0; g < ngrp - 1; ++g) {
             BSP_HIP(hipEventCreateWithFlags(&evj[g], hipEventDisableTiming));
-            BSP_HIP(hipEventRecord(evj[g], s_aux[g]));
+            BSP_HIP(hipEventRecord(evj[g], aux[g]));
             BSP_HIP(hipStreamWaitEvent(st, evj[g], 0));
         }
         hipEventDestroy(evf);                                              // released once the work recorded so far has passed them

@@ -10,7 +10,7 @@
 //
 // Output normalisation: c^T S c = 1 (DSYGV ITYPE=1), sign chosen so that the first significant
 // coefficient is positive (LAPACK's sign is arbitrary; CHKPHS is commented out, matrices.f90:382).
-#include "common.h"
+#include "bandsect.h"
 
 namespace bsp {
 
@@ -61,25 +61,14 @@ __device__ __forceinline__ double ev_row0_max(double x)          // max over lan
 // round trip into every column of the factorisation.
 __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// BT >= b = k - 1: rows of the register window (instances 8 and 15)
+// BT >= b = k - 1: rows of the register window (instances 8 and 15).  One wavefront (lane = its lane); y: n doubles of LDS; work:
+// n (3 b + 3) doubles; *info <- iv + 1 if the iterate vanished.
 template <int BT>
-__global__ __launch_bounds__(64) void invit_kernel(int n, int k, const double *__restrict__ SB,
-                                                  const double *__restrict__ HBall,
-                                                  const int *__restrict__ chan, const double *__restrict__ Eall,
-                                                  double *workall, double *vecall, int *info)
+__device__ __forceinline__ void invit_body(int n, int k, const double *__restrict__ SB, const double *__restrict__ HB, const double E,
+                                           double *work, double *vec, int *info, int iv, double *y, const int lane)
 {
-    extern __shared__ double y[];                       // n doubles
-    // one wavefront on a chain of dependent steps, usually beside the batched bisection whose waves are pure VALU work:
-    // issue priority over them
-    __builtin_amdgcn_s_setprio(3);
-    const int lane = threadIdx.x;
     const int b = k - 1;
-    const size_t iv = blockIdx.x;
-    const double E = Eall[iv];
-    const double *HB = HBall + (size_t)chan[iv] * k * n;
-    double *work = workall + iv * ((size_t)n * (3 * b + 3));
     double *U = work, *Lm = work + (size_t)n * (2 * b + 1), *piv = Lm + (size_t)n * b, *tmp = piv + n;
-    double *vec = vecall + iv * (size_t)n;
 
     // scale for the zero-pivot perturbation: ~ eps * max|M_jj|
     double dmax = 0.0;
@@ -294,9 +283,41 @@ __global__ __launch_bounds__(64) void invit_kernel(int n, int k, const double *_
     for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(first, off); first = o < first ? o : first; }
     double sgn = 1.0;
     if (first < n && y[first] < 0.0) sgn = -1.0;
-    if (!(q > 0.0)) { if (lane == 0) atomicExch(info, (int)iv + 1); q = 1.0; }
+    if (!(q > 0.0)) { if (lane == 0) atomicExch(info, iv + 1); q = 1.0; }
     const double nrm = sgn / sqrt(q);
     for (int j = lane; j < n; j += 64) vec[j] = y[j] * nrm;
+}
+
+template <int BT>
+__global__ __launch_bounds__(64) void invit_kernel(int n, int k, const double *__restrict__ SB, const double *__restrict__ HBall,
+                                                  const int *__restrict__ chan, const double *__restrict__ Eall,
+                                                  double *workall, double *vecall, int *info)
+{
+    extern __shared__ double y[];                       // n doubles
+    // one wavefront on a chain of dependent steps, usually beside the batched bisection whose waves are pure VALU work:
+    // issue priority over them
+    __builtin_amdgcn_s_setprio(3);
+    const int iv = blockIdx.x, b = k - 1;
+    invit_body<BT>(n, k, SB, HBall + (size_t)chan[iv] * k * n, Eall[iv], workall + (size_t)iv * ((size_t)n * (3 * b + 3)),
+                   vecall + (size_t)iv * n, info, iv, y, threadIdx.x);
+}
+
+// The consumed eigenvector EARLY (capi.hip::solve_impl, band route): eigenvalue m of the pencil of one channel by multisection on its
+// inertia (bandsect.h: 256 threads), then the inverse iteration by the first wavefront of the SAME workgroup while the others leave.
+// One launch, because the workgroup asks for a CU's whole LDS (own_lds bytes of dynamic LDS it never touches): it runs beside the
+// band reduction, whose 3000 launches each wait for their slowest wave -- and a wave that shares its SIMD with one of these runs
+// at two thirds of its speed (measured: reduction 28 -> 31 ms; at a lower priority these waves took 30 ms instead of 17 and were
+// still holding LDS when the chase needed every slot of the chip).  The CU is claimed while the reduction's first launches are
+// still small, and kept: two launches would have to find a drained CU twice.  1 / 256 of the chip for 17 ms.
+__global__ __launch_bounds__(BS_T) void early_vector_kernel(int n, int k, const double *__restrict__ SB, const double *__restrict__ HB,
+                                                           int m, double *Eout, double *work, double *vec, int *info)
+{
+    extern __shared__ double y[];                       // n doubles (and the padding up to a CU's LDS)
+    __shared__ BandSectLds L;
+    const double lam = band_multisect(n, k, SB, HB, m, L);
+    if (threadIdx.x == 0) *Eout = lam;
+    if (threadIdx.x >= 64) return;                      // (a barrier counts the waves that are left)
+    invit_body<BS_B>(n, k, SB, HB, lam, work, vec, info, 0, y, threadIdx.x);
 }
 
 size_t invit_work_doubles(int n, int k) { return (size_t)n * (3 * (k - 1) + 3); }
@@ -317,6 +338,25 @@ int launch_inverse_iteration(int n, int k, int nvec, const double *d_SB, const d
     }
     if (k - 1 <= 8) hipLaunchKernelGGL(invit_kernel<8>, dim3(nvec), dim3(64), lds, st, n, k, d_SB, d_HB, d_chan, d_E, d_work, d_vec, d_info);
     else hipLaunchKernelGGL(invit_kernel<EB_MAX>, dim3(nvec), dim3(64), lds, st, n, k, d_SB, d_HB, d_chan, d_E, d_work, d_vec, d_info);
+    BSP_HIP(hipGetLastError());
+    return BSP_OK;
+}
+
+// eigenvalue m (0-based) of the pencil (d_HB: ONE channel's band) -> *d_E, its eigenvector -> d_vec; d_work as above for one vector
+int launch_early_vector(int n, int k, const double *d_SB, const double *d_HB, int m, double *d_E, double *d_work, double *d_vec,
+                        int *d_info, hipStream_t st, bool own_cu)
+{
+    if (k < 2 || k - 1 > BS_B || m < 0 || m >= n) return BSP_ERR_UNSUPPORTED;
+    size_t lds = (size_t)n * sizeof(double);
+    const size_t stat = sizeof(BandSectLds), room = 160 * 1024 - stat - 512;
+    if (lds > room) return BSP_ERR_UNSUPPORTED;
+    if (own_cu && lds + stat < OWN_CU_LDS) lds = OWN_CU_LDS - stat;
+    static bool attr_set = false;
+    if (!attr_set) {
+        BSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(early_vector_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)room));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(early_vector_kernel, dim3(1), dim3(BS_T), lds, st, n, k, d_SB, d_HB, m, d_E, d_work, d_vec, d_info);
     BSP_HIP(hipGetLastError());
     return BSP_OK;
 }

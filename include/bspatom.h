@@ -121,6 +121,11 @@ int bspatom_dipole_elements(bspatom_problem *p, int l_ini, int n0_ini, int l_fin
  * i = 0..npts.  Returns BSPATOM_ERR_BSPLVB where the reference STOPs. r[npts+1], u[npts+1]. */
 int bspatom_write_wf(bspatom_problem *p, const double *c, int npts, double *r, double *u);
 
+/* The eigenvector the reference consumes (l_ini, n0_ini; matrices.f90:267) is computed during bspatom_solve when its channel is in
+ * the batch.  On the band route its eigenvalue comes from the pencil's inertia right after the assembly (csrc/bandsect.hip), and the
+ * solve checks it against the spectra when they are there.  state of the last solve: 0 = no early vector (other route, channel not in
+ * the batch, BSP_VEC_EARLY=0), 1 = early vector kept, -1 = check failed, vector dropped (bspatom_eigvec computes it on demand). */
+int bspatom_early_vector_state(const bspatom_problem *p, int32_t *state);
 /* Per-stage device time of the last bspatom_solve* call, HIP events on the library's stream
  * (milliseconds): [0] point table + bands, [1] Cholesky + standard form, [2] sy2sb,
  * [3] sb2st, [4] bisection, [5] total.  Also the number of launches of the sy2sb GEMM. */
@@ -203,6 +208,10 @@ int bspatom_stage_sb2sb(int n, int npad, int batch, double *AB);
  * minor at which the factorisation of the (index-reversed) overlap broke down.  Replaces DPOTRF + DSYGST + the dense stage of
  * DSYTRD inside DSYGV (matrices.f90:248) in 6 n^2 (k - 1) flop and no dense matrix. */
 int bspatom_stage_crawford(int n, int k, int nl, const double *SB, const double *HB, double *AB, int32_t *info);
+/* eigenvalue m (0-based, ascending) of ONE banded pencil (H, S), upper bands as bspatom_assemble returns them, k - 1 <= 8, by
+ * multisection on the inertia of H - x S (csrc/bandsect.hip): what starts the inverse iteration for the eigenvector the reference
+ * consumes (matrices.f90:267) while the reductions of the batch are still running */
+int bspatom_stage_band_eigenvalue(int n, int k, const double *SB, const double *HB, int m, double *lambda);
 /* eigenvalues of tridiagonal matrices, ascending */
 int bspatom_stage_bisect(int n, int batch, const double *d, const double *e, double *w);
 

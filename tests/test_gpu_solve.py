@@ -189,6 +189,39 @@ def test_eigvec_and_wf(name):
     prob.close()
 
 
+@pytest.mark.parametrize("name,over", [("c3_1024_l31", dict(l_ini=3, n0_ini=40)), ("c3_1024_l31", dict(l_ini=0, n0_ini=1)),
+                                       ("lin256", dict(l_ini=1, n0_ini=256)), ("c1_exp", dict()), ("n65_k4", dict())])
+def test_early_eigenvector(name, over):
+    """Band route: the consumed eigenvector with its eigenvalue from the pencil's inertia right after the assembly (csrc/bandsect.hip,
+    BSP_VEC_EARLY) against the one whose eigenvalue comes from the tridiagonal matrix at the end of the pipeline, and against the
+    fallback (the check made to fail: bspatom_eigvec computes the vector on demand from the spectra)."""
+    inp = input_from_case(name, **over)
+    prob = capi.Problem(inp)
+    if prob.route() != 2:
+        pytest.skip("dense route")
+    nl = prob.lmax + 1
+    E, info = prob.solve(0, nl)
+    assert np.all(info == 0) and prob.early_vector_state() == 1
+    c1 = prob.eigvec(inp.l_ini, inp.n0_ini)
+    with _Options(vec_early=0):
+        E0, _ = prob.solve(0, nl)
+        assert prob.early_vector_state() == 0
+        c0 = prob.eigvec(inp.l_ini, inp.n0_ini)
+    with _Options(vec_early=2):
+        E2, _ = prob.solve(0, nl)
+        assert prob.early_vector_state() == 1            # the value passed; the vector was dropped on purpose
+        c2 = prob.eigvec(inp.l_ini, inp.n0_ini)
+    assert np.array_equal(E, E0) and np.array_equal(E, E2)
+    for c in (c0, c2):
+        s = np.sign(np.dot(c, c1))
+        assert np.max(np.abs(s * c - c1)) <= 1e-9 * np.max(np.abs(c1)), name
+    # a channel outside the batch: no early vector
+    if inp.l_ini + 1 <= prob.lmax:
+        prob.solve(inp.l_ini + 1, 1)
+        assert prob.early_vector_state() == 0
+    prob.close()
+
+
 def test_wf_fatal_edge_case():
     """Reference STOPs in BSPLVB when the last tabulation point rounds above rb: same status here."""
     prob = capi.Problem(input_from_case("wf_fatal"))

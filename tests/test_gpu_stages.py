@@ -513,6 +513,27 @@ def test_crawford_band(n, k, nl):
             assert err < 2e-14 * np.sqrt(n)                      # both sides carry ~eps cond(S) |lambda|_max
 
 
+@pytest.mark.parametrize("n,k,seed", [(64, 9, 1), (200, 9, 2), (1000, 9, 3), (333, 4, 4), (77, 2, 5)])
+def test_band_eigenvalue_from_inertia(n, k, seed):
+    """csrc/bandsect.hip: single eigenvalues of a banded pencil by multisection on the inertia of H - x S (no pivoting) against scipy's
+    eigh of the dense pencil -- the smallest, the largest, ones next to zero and a sample in between."""
+    import scipy.linalg as sla
+    SB, HB = _random_pencil(n, k, 1, seed)
+    ref = sla.eigh(_dense_upper(HB[0]), _dense_upper(SB), eigvals_only=True)
+    width = np.max(np.abs(ref))
+    rng = np.random.default_rng(seed)
+    near0 = int(np.argmin(np.abs(ref)))
+    ms = sorted(set([0, 1, n - 1, n - 2, near0, max(near0 - 1, 0), min(near0 + 1, n - 1)] + [int(i) for i in rng.integers(0, n, 6)]))
+    worst = 0.0
+    for m in ms:
+        lam = capi.stage_band_eigenvalue(SB, HB[0], m)
+        worst = max(worst, abs(lam - ref[m]) / width)
+    note("band eigenvalue from inertia n %d k %d: worst |lambda - eigh| / |lambda|_max over %d eigenvalues %.2e" % (n, k, len(ms), worst))
+    assert worst < 1e-13 * np.sqrt(n)
+    with pytest.raises(capi.BspAtomError):
+        capi.stage_band_eigenvalue(SB, HB[0], n)
+
+
 def test_crawford_not_positive_definite():
     SB, HB = _random_pencil(64, 9, 1, 5)
     SB[0, 20] = -1.0
