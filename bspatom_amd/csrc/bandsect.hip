@@ -10,8 +10,9 @@
 // with L D L^T taken WITHOUT pivoting along the band (half-width b <= 8: a window of (b + 1)(b + 2) / 2 entries per shift in
 // registers, one new row of the band per step).  256 shifts per round -- one per thread, all walking the same rows, which a
 // workgroup stages through LDS 64 rows at a time -- so a bracket shrinks 257-fold per round: a first round on the powers of two of both
-// signs, seven more to 2 eps |x|.  ~8 ms of one workgroup, right after the assembly, with 60 ms of reductions ahead of it: the
-// vector is there long before the spectra are.
+// signs, seven more to 2 eps |x|.  8.3 ms of one workgroup, right after the assembly, with 60 ms of reductions ahead of it; the
+// inverse iteration follows in the same workgroup (eigvec.hip::early_vector_kernel -- the device code is in bandsect.h for that;
+// the kernel of this file serves the stage entry bspatom_stage_band_eigenvalue): the vector is there long before the spectra are.
 //
 // Without pivoting the factorisation can grow (|L| up to 1e6 on C4's pencil at unlucky shifts) and a count can then be off next to an
 // eigenvalue; the search needs no monotonicity (lo = the point before the FIRST point whose count exceeds m), its result is an

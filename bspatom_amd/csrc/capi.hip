@@ -550,8 +550,9 @@ static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, dou
     } else if ((rc = enqueue_assemble(p, l0, nl))) return rc;
     BSP_HIP(hipEventRecord(p->ev[1], p->st));
     // The consumed eigenvector (l_ini, n0_ini).  Band route (BSP_VEC_EARLY): its eigenvalue from the PENCIL, by multisection on the
-    // inertia of H - x S (bandsect.hip), as soon as the channel is assembled, the inverse iteration behind it, both on a side stream
-    // beside the reductions -- the vector is there long before the spectra, and checked against them below.  Otherwise: the
+    // inertia of H - x S (bandsect.hip), as soon as the channel is assembled, the inverse iteration behind it, one workgroup on a CU
+    // of its own (eigvec.hip::early_vector_kernel) beside the reductions -- the vector is there long before the spectra, and checked
+    // against them below.  Otherwise: the
     // eigenvalue alone by multisection as soon as the tridiagonal matrices exist, then the inverse iteration on the side stream
     // beside the batched bisection.
     p->pre_l = -1; p->pre_early = false;

@@ -537,8 +537,8 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void crawford_item4_kernel(int N, 
                                                             int nlead, const double *__restrict__ Qel, double *Dall, double *Eall, double *Gall,
                                                             unsigned long long *diag)
 {
-    // a launch waits for its slowest wave: the waves of these launches go first on a SIMD they share with the long-running single
-    // workgroups of the consumed eigenvector (bandsect.hip, eigvec.hip: priority 0), which have 60 ms to spare
+    // a launch waits for its slowest wave: the waves of these launches go first on a SIMD they share with a long-running wave of
+    // another kernel (the consumed eigenvector's workgroup if it was not given a CU of its own, BSP_VEC_OWN_CU=0: it has 60 ms to spare)
     __builtin_amdgcn_s_setprio(3);
     // BSP_CW_DIAG: s_memtime stamps of a wave's phases, summed over the waves of every launch (diag[0..6] ticks, diag[7] waves)
     if (diag && (((blockIdx.x & 7) | (blockIdx.y & 7)) != 0)) diag = nullptr;   // one wave in 64 reports (the sums are atomics)

@@ -1115,8 +1115,8 @@ __global__ __launch_bounds__(SB16R_THREADS) void sbr_rows_kernel(int n, int npad
     constexpr int WSH = W::WSH, WR = W::WR, RPW = W::RPW, NSW = W::NSW, MLAG = W::MLAG, LP0 = W::LP0;
     extern __shared__ double lds[];
     double *Lw = lds;
-    // the whole batch waits for the slowest channel: first on a SIMD shared with the consumed eigenvector's single workgroups (as the
-    // band reduction's waves, crawford.hip)
+    // the whole batch waits for the slowest channel: first on a SIMD shared with a long-running wave of another kernel (as the band
+    // reduction's waves, crawford.hip)
     __builtin_amdgcn_s_setprio(3);
     long long dacc[5] = {0, 0, 0, 0, 0}, dt0 = 0;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
