@@ -368,13 +368,14 @@ def flop_band(n):
     chase items (N-1)(N-2)/2 with N = ceil(n/8), each the RQ of an 8 x 16 block (2*16*64 - 2/3*512), its 16 x 16 factor formed
     (8 reflectors x 4*256), the congruence Q^T (W Q) (2 products of 2*16^3) and Q^T [E; 0] (2*16*8*8); N - 1 eliminations (the two
     products and the two small ones); band of half-width 8 -> tridiagonal: 6 n^2 8; bisection: 54 Sturm counts of n rows for n
-    eigenvalues, 3 fp64 operations per row -- until round 4's secant rounds: now 32 evaluation rounds of a workgroup's 1024 slots
-    (the first-level grid, ~24 lock-step rounds, 6 - 9 rounds of the multisection tail)."""
+    eigenvalues, 3 fp64 operations per row -- until round 4's secant rounds (32 evaluation rounds of a workgroup's 1024 slots) and
+    shared points: now ~22 rounds (~15 lock-step rounds until an eighth of the brackets are left, ~7 of the multisection tail;
+    the kernel's VALU instruction count / that of one round, profiles/r04_band_valu_util.txt)."""
     N = (n + 7) // 8
     item = (2 * 16 * 64 - 2.0 / 3.0 * 512) + 8 * 4 * 256 + 2 * 2 * 16 ** 3 + 2 * 16 * 8 * 8
     elim = 2 * 2 * 16 ** 3 + 2 * 2 * 16 * 8 * 8
     return {"band_reduction": (N - 1) * (N - 2) / 2.0 * item + (N - 1) * elim, "band_chase": 6.0 * n * n * 8,
-            "bisect": 32.0 * 3.0 * n * n}
+            "bisect": 22.0 * 3.0 * n * n}
 
 
 def dense_kernel_entries(ktimes, npad, nl, pmc_bytes, pmc_file, pmc_stale, mfma, mfma_file, mfma_stale):
@@ -551,8 +552,8 @@ def report(args, world, n, npad, main, ktimes, kstage, route):
             kern.append({"kernel": "bisect3_kernel", "bound": "mfma", "launches_per_step": calls, "avg_launch_ms": ms_sum / calls,
                          "kernel_ms_per_step": ms_sum, "launch_ms_source": src_live, "flop_per_step": fb["bisect"] * nl, "achieved": ach,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
-                         "limited_by": "fp64 vector pipe: 3 fp64 + ~1.6 other instructions per row and eigenvalue; ~19 evaluations per eigenvalue, "
-                                       "~32 rounds per workgroup in lock step (DESIGN 4.3)"})
+                         "limited_by": "fp64 vector pipe: 3 fp64 + ~1.6 other instructions per row and eigenvalue; ~12 - 15 evaluations per eigenvalue, "
+                                       "~22 rounds per workgroup in lock step (DESIGN 4.3)"})
         F = sum(fb.values())
         ach = F * main["value"] / 1e12
         ceiling = FP64_PEAK_TFLOPS * 1e12 * world / flop_dense(n, args.k)
