@@ -576,6 +576,12 @@ static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, dou
         // this one, the reduction's second group's and a fourth -- two of them share a hardware queue: the reduction's second group
         // then waited behind these 20 ms, measured, 28 -> 44 ms; and the second group on THIS stream starts 1.5 ms late: 28 -> 31 ms)
         hipStream_t sv = s_prepared ? p->stS : p->st2;
+        // a CU of its own only where the chase has no CU to spare for it -- more than 32 channels: fewer than eight workgroups per channel
+        // or two per CU.  Below that the reduction is over before the vector is, the chase would lose the CU (32 channels: chase 13.9 ->
+        // 15.9 ms), and a shared CU has room for both (with 64 channels and a shared CU: chase 16.8 -> 22.5 ms).
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
+        const bool own_cu = opts().vec_own_cu == 2 || (opts().vec_own_cu == 1 && ((nl + 7) / 8) * 8 * 8 > cus);
         BSP_HIP(hipMemsetAsync(p->d_pinfo, 0, sizeof(int), sv));
         if (s_prepared && tl == l0) BSP_HIP(hipStreamWaitEvent(sv, p->evS, 0));     // its channel was assembled first, S with it
         else {
@@ -583,7 +589,7 @@ static int solve_impl(bspatom_problem *p, int l0, int nl, double *E_dev_out, dou
             BSP_HIP(hipStreamWaitEvent(sv, p->evx, 0));
         }
         if ((rc = launch_early_vector(n, h.k, p->d_SB, p->d_HB + (size_t)p->pre_ch * h.k * n, tn0 - 1, p->d_pE, p->d_vwork, p->d_pvec,
-                                      p->d_pinfo, sv, opts().vec_own_cu != 0))) return rc;
+                                      p->d_pinfo, sv, own_cu))) return rc;
         BSP_HIP(hipEventRecord(p->evx, sv));
         p->pre_l = tl; p->pre_n0 = tn0; p->pre_early = true;
     }

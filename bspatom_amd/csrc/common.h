@@ -58,7 +58,7 @@ struct Options {
     int bisect_tail = 1;         // BSP_BISECT_TAIL: 0 = lock-step bisection to the end (no multisection tail), for A/B timing
     int no_eigvec_prefetch = 0;
     int vec_early = 1;           // BSP_VEC_EARLY: band route, the consumed eigenvector's eigenvalue from the pencil's inertia right after the assembly (bandsect.hip); 0: from the tridiagonal matrix at the end; 2: as 1 with the check made to fail
-    int vec_own_cu = 1;          // BSP_VEC_OWN_CU: the early vector's workgroup asks for a CU's whole LDS (eigvec.hip::early_vector_kernel)
+    int vec_own_cu = 1;          // BSP_VEC_OWN_CU: the early vector's workgroup asks for a CU's whole LDS (eigvec.hip::early_vector_kernel) -- 1: for batches of more than 32 channels (capi.hip), 2: always, 0: never
     int sb2sb_mfma = 1;          // 1: block-chasing item on the matrix cores (sbr2.hip); 0: the first, all-VALU kernel (cross-check)
     int sb16_rows = 1;           // BSP_SB16_ROWS: 1 = band 16 -> 1 with a whole chase item per DPP row, four sweeps per wave (sbr2.hip); 0 = the
                                  // first layout (one tile spread over a wave), kept as the cross-check
