@@ -121,6 +121,7 @@ __global__ __launch_bounds__(64 * PT_WPB) void point_table_kernel(
 }
 
 constexpr int BAND_LCH = 16;  // channels per workgroup (grid.y chunks the l range)
+constexpr int BAND_LG = 4;    // channels per item (they share the item's reads of the point table)
 
 // TI = band rows per workgroup (runtime: chosen so that the staged table fits in LDS)
 __global__ __launch_bounds__(256) void band_kernel(int TI, int nfun, int k, int ka, int nkp, int kind_pot,
@@ -148,23 +149,36 @@ __global__ __launch_bounds__(256) void band_kernel(int TI, int nfun, int k, int 
     __syncthreads();
 
     const int nrow = (nfun - i0 < TI) ? (nfun - i0) : TI;
-    const int items = TI * k * lcnt;
+    // One item = one band entry (row ii, diagonal d) for BAND_LG consecutive channels: the basis values, r, dr and the potential of
+    // a quadrature point are read from LDS once for the group (the kernel is bound by those reads -- seven per point and entry, at
+    // irregular addresses: one entry per channel and item took 1.37 ms for 127 channels of n = 4096, all of it in front of the
+    // reduction), the sums S, V, T are the same for every channel, and only the centrifugal sum has a term per channel.  Every sum
+    // adds the same terms in the same order as before: the same bits (tests/test_gpu_stages.py: the bands against the golden files and the oracle, bit for bit).
+    const int ngrp = (lcnt + BAND_LG - 1) / BAND_LG;
+    const int items = TI * k * ngrp;
     for (int it = threadIdx.x; it < items; it += blockDim.x) {
         const int ii = it % TI;
         const int d = (it / TI) % k;
-        const int l = lbeg + it / (TI * k);
+        const int lg = it / (TI * k);
+        const int lfirst = lbeg + lg * BAND_LG;
+        const int ln = (lbeg + lcnt - lfirst < BAND_LG) ? (lbeg + lcnt - lfirst) : BAND_LG;
         if (ii >= nrow) continue;
         const int ibra = i0 + ii + 1, jket = ibra + d;        // 1-based
         const size_t off = (size_t)d * nfun + (ibra - 1);
         if (jket > nfun) {
-            if (l == 0) SB[off] = 0.0;
-            HB[(size_t)l * k * nfun + off] = 0.0;
+            if (lfirst == 0) SB[off] = 0.0;
+            for (int u = 0; u < ln; ++u) HB[(size_t)(lfirst + u) * k * nfun + off] = 0.0;
             continue;
         }
-        const int lfq = l0 + l;
-        const double cl = (double)((long long)lfq * (lfq + 1));
-        const double blv = (kind_pot == 2 && lfq <= 3) ? bl[lfq] : 0.0;
-        double sumS = 0.0, sumV = 0.0, sumT = 0.0, sumU = 0.0;
+        double cl[BAND_LG], blv[BAND_LG], sumU[BAND_LG];
+#pragma unroll
+        for (int u = 0; u < BAND_LG; ++u) {
+            const int lfq = l0 + lfirst + u;
+            cl[u] = (double)((long long)lfq * (lfq + 1));
+            blv[u] = (kind_pot == 2 && lfq <= 3) ? bl[lfq] : 0.0;
+            sumU[u] = 0.0;
+        }
+        double sumS = 0.0, sumV = 0.0, sumT = 0.0;
         for (int ibet = jket; ibet <= ibra + k - 1; ++ibet) {
             const double *eb = tab + (size_t)(ibet - ib0) * ka * W;
             const int *lb = lf + (ibet - ib0) * ka;
@@ -180,14 +194,19 @@ __global__ __launch_bounds__(256) void band_kernel(int TI, int nfun, int k, int 
                 sumS = sumS + fbra * fket * dr;                       // matrices.f90:145
                 sumV = sumV + fbra * Vpot * fket * dr;                // :146
                 sumT = sumT + dfbra * 0.5 * dfket * dr;               // :147
-                const double Vcent = cl / (2.0 * (r * r));            // :149
-                double Vl = 0.0;
-                if (kind_pot == 2) Vl = blv / (r * r);                // :151
-                sumU = sumU + fbra * (Vcent + Vl) * fket * dr;        // :152
+#pragma unroll
+                for (int u = 0; u < BAND_LG; ++u) {
+                    const double Vcent = cl[u] / (2.0 * (r * r));     // :149
+                    double Vl = 0.0;
+                    if (kind_pot == 2) Vl = blv[u] / (r * r);         // :151
+                    sumU[u] = sumU[u] + fbra * (Vcent + Vl) * fket * dr;   // :152
+                }
             }
         }
-        if (l == 0) SB[off] = sumS;                                   // :180
-        HB[(size_t)l * k * nfun + off] = (sumT + sumU) + sumV;        // :244  Tij + Uij(l) + Vij
+        if (lfirst == 0) SB[off] = sumS;                              // :180
+#pragma unroll
+        for (int u = 0; u < BAND_LG; ++u)
+            if (u < ln) HB[(size_t)(lfirst + u) * k * nfun + off] = (sumT + sumU[u]) + sumV;   // :244  Tij + Uij(l) + Vij
     }
 }
 
